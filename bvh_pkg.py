@@ -1,0 +1,17 @@
+"""Loader for the hyphen-named package directory ``hip-bvh-construction_amd`` (import name ``hip_bvh_construction_amd``)."""
+import importlib.util
+import os
+import sys
+
+_NAME = "hip_bvh_construction_amd"
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip-bvh-construction_amd")
+
+
+def load():
+    if _NAME in sys.modules:
+        return sys.modules[_NAME]
+    spec = importlib.util.spec_from_file_location(_NAME, os.path.join(_DIR, "__init__.py"), submodule_search_locations=[_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,280 @@
+"""hip-bvh-construction_amd — MI355X-native BVH construction (LBVH / PLOC++ / HPLOC) behind the reference's builder API.
+
+The product is the C-ABI shared library ``libbvh_mi355x.so`` (HIP kernels for gfx950, ``csrc/``; header
+``include/bvh_mi355x.h``).  This Python package is only the test / bench harness around it: a ctypes binding plus a
+mirror of the reference's builder classes (``TwoPassLbvh`` / ``SinglePassLbvh`` / ``PLOCNew`` / ``HPLOC`` ``.build(context,
+triangles)``, reference ``src/TwoPassLbvh.h:12-32`` etc.) so that parity tests read like the reference's own driver
+(``src/main.cpp:52-65``).  The C++ mirror of the same classes is ``include/bvh/builders.hpp``.
+
+There is no CPU fallback: every entry point fails loudly (``BvhError``) if the native library or a GPU is missing.
+The directory name contains a hyphen; import it with ``bvh_pkg.load()`` from the repo root (or importlib).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import meshgen  # noqa: F401
+from .meshgen import TRIANGLE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbvh_mi355x.so")
+
+AABB = np.dtype([("min", "<f4", 3), ("max", "<f4", 3)])
+BVH2_NODE = np.dtype([("left", "<u4"), ("right", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
+PRIMREF = np.dtype([("prim", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
+assert AABB.itemsize == 24 and BVH2_NODE.itemsize == 32 and PRIMREF.itemsize == 28
+INVALID = 0xFFFFFFFF
+
+ALGO_TWOPASS, ALGO_SINGLEPASS, ALGO_PLOCPP, ALGO_HPLOC = 0, 1, 2, 3
+ALGO_NAMES = {0: "TwoPassLbvh", 1: "SinglePassLbvh", 2: "PLOCNew", 3: "HPLOC"}
+
+# every symbol include/bvh_mi355x.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
+    "bvh_ctx_set_profiling", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
+    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_sah_cost",
+    "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_version",
+]
+
+
+class BvhError(RuntimeError):
+    pass
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_extents", C.c_float), ("ms_morton", C.c_float), ("ms_sort", C.c_float), ("ms_build", C.c_float),
+                ("ms_collapse", C.c_float), ("ms_total", C.c_float), ("ploc_iterations", C.c_uint32), ("reserved", C.c_uint32),
+                ("bytes_algorithmic", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("d_nodes", C.c_void_p), ("d_leaves", C.c_void_p), ("d_prim_aabbs", C.c_void_p), ("d_scene_extent", C.c_void_p),
+                ("d_sorted_keys", C.c_void_p), ("d_sorted_vals", C.c_void_p), ("root", C.c_uint32), ("n_internal", C.c_uint32),
+                ("n_leaves", C.c_uint32), ("layout", C.c_uint32)]
+
+
+def build_native(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libbvh_mi355x.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise BvhError("native build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the native library; raises BvhError if it is not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BvhError(f"{LIB_PATH} is missing — run __graft_entry__.build() (make -C hip-bvh-construction_amd/csrc); there is no CPU fallback")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise BvhError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, u32, i32, u64 = C.c_void_p, C.c_uint32, C.c_int, C.c_uint64
+    sig = {
+        "bvh_ctx_create": ([i32, C.POINTER(vp)], i32), "bvh_ctx_create_on_stream": ([i32, vp, C.POINTER(vp)], i32),
+        "bvh_ctx_destroy": ([vp], None), "bvh_ctx_reserve": ([vp, u32], i32), "bvh_ctx_device": ([vp], i32),
+        "bvh_ctx_stream": ([vp], vp), "bvh_ctx_set_profiling": ([vp, i32], i32), "bvh_ctx_synchronize": ([vp], i32),
+        "bvh_build": ([vp, i32, vp, u32, i32, C.POINTER(Result), C.POINTER(Timings)], i32),
+        "bvh_stage_extents": ([vp, vp, u32, vp, vp], i32), "bvh_stage_morton": ([vp, vp, u32, vp, vp, vp], i32),
+        "bvh_sort_pairs": ([vp, vp, vp, u32, vp, vp, i32, i32], i32),
+        "bvh_emit_lbvh_single": ([vp, vp, vp, vp, u32, vp, C.POINTER(u32)], i32),
+        "bvh_emit_lbvh_two": ([vp, vp, vp, vp, u32, vp], i32),
+        "bvh_emit_ploc": ([vp, vp, vp, u32, vp, vp, C.POINTER(u32)], i32),
+        "bvh_emit_hploc": ([vp, vp, vp, vp, u32, vp, vp], i32),
+        "bvh_to_lbvh_layout": ([vp, C.POINTER(Result), vp], i32), "bvh_sah_cost": ([vp, C.POINTER(Result), C.POINTER(C.c_double)], i32),
+        "bvh_download": ([vp, C.POINTER(Result), vp, vp, vp, vp, vp], i32),
+        "bvh_dev_alloc": ([vp, u64, C.POINTER(vp)], i32), "bvh_dev_free": ([vp, vp], i32),
+        "bvh_dev_upload": ([vp, vp, vp, u64], i32), "bvh_dev_download": ([vp, vp, vp, u64], i32),
+        "bvh_version": ([], C.c_char_p),
+    }
+    for name, (args, res) in sig.items():
+        f = getattr(L, name)
+        f.argtypes, f.restype = args, res
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise BvhError(f"{what} failed with code {rc}" + (" (hipError %d)" % -rc if -1000 < rc < 0 else ""))
+
+
+def _ptr(a) -> int:
+    """Device pointer of a torch tensor / int, or host pointer of a numpy array."""
+    if a is None:
+        return 0
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+class DeviceBuffer:
+    """A device allocation made through the C ABI (no torch needed)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _check(lib().bvh_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p)), "bvh_dev_alloc")
+        self.ptr = p.value
+
+    def upload(self, host: np.ndarray) -> "DeviceBuffer":
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        _check(lib().bvh_dev_upload(self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes), "bvh_dev_upload")
+        return self
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        _check(lib().bvh_dev_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "bvh_dev_download")
+        return out
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().bvh_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """Mirror of the reference's ``Context`` (src/Context.h:8-18): owns the device binding; here also stream + arena."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        if stream:
+            _check(lib().bvh_ctx_create_on_stream(device, stream, C.byref(h)), "bvh_ctx_create_on_stream")
+        else:
+            _check(lib().bvh_ctx_create(device, C.byref(h)), "bvh_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def set_profiling(self, on: bool) -> None:
+        _check(lib().bvh_ctx_set_profiling(self.handle, int(on)), "bvh_ctx_set_profiling")
+
+    def reserve(self, n: int) -> None:
+        _check(lib().bvh_ctx_reserve(self.handle, n), "bvh_ctx_reserve")
+
+    def synchronize(self) -> None:
+        _check(lib().bvh_ctx_synchronize(self.handle), "bvh_ctx_synchronize")
+
+    def upload(self, host: np.ndarray) -> DeviceBuffer:
+        return DeviceBuffer(self, host.nbytes).upload(host)
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def close(self) -> None:
+        if self.handle:
+            lib().bvh_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Builder:
+    """Common part of the four builders.  After ``build``: ``m_rootNodeIdx``, ``m_nInternalNodes``, ``m_timer`` (dict of
+    the reference's TimerCodes tokens -> ms), and device pointers ``d_bvhNodes`` / ``d_leafNodes`` /
+    ``d_sortedMortonCodeKeys`` / ``d_sortedMortonCodeValues`` / ``d_triangleAabb`` / ``d_sceneExtents`` as plain ints."""
+    ALGO = -1
+
+    def __init__(self):
+        self.result = Result()
+        self.timings = Timings()
+        self.m_rootNodeIdx = 0
+        self.m_nInternalNodes = 0
+        self.m_cost = 0.0
+        self.m_timer = {}
+        self._ctx = None
+
+    def build(self, context: Context, primitives, on_device: bool = False, n: int | None = None) -> "_Builder":
+        """``primitives``: numpy array of dtype TRIANGLE (host; copied H2D untimed like the reference) or, with
+        ``on_device=True``, anything with ``data_ptr()`` / an int device address plus ``n``."""
+        if isinstance(primitives, np.ndarray):
+            if primitives.dtype != TRIANGLE:
+                raise BvhError("primitives must have dtype TRIANGLE (64-byte records)")
+            primitives = np.ascontiguousarray(primitives)
+            n = primitives.shape[0]
+            on_device = False
+        elif n is None:
+            raise BvhError("n is required for device inputs")
+        self._ctx = context
+        _check(lib().bvh_build(context.handle, self.ALGO, _ptr(primitives), n, int(on_device), C.byref(self.result), C.byref(self.timings)),
+               f"{ALGO_NAMES[self.ALGO]}::build")
+        r, t = self.result, self.timings
+        self.m_rootNodeIdx, self.m_nInternalNodes = r.root, r.n_internal
+        self.d_bvhNodes, self.d_leafNodes = r.d_nodes, r.d_leaves
+        self.d_sortedMortonCodeKeys, self.d_sortedMortonCodeValues = r.d_sorted_keys, r.d_sorted_vals
+        self.d_triangleAabb, self.d_sceneExtents = r.d_prim_aabbs, r.d_scene_extent
+        self.m_timer = {"CalculateCentroidExtentsTime": t.ms_extents, "CalculateMortonCodesTime": t.ms_morton, "SortingTime": t.ms_sort,
+                        "BvhBuildTime": t.ms_build, "CollapseBvhTime": t.ms_collapse, "TotalTime": t.ms_total}
+        return self
+
+    # ---- read-backs (the reference's d_x.getData()) ------------------------------------------------------------
+    def download(self):
+        """-> dict(nodes, leaves (or None), sorted_keys, sorted_vals, scene) as numpy arrays."""
+        r = self.result
+        n = r.n_leaves
+        nodes = np.empty(2 * n - 1 if r.layout == 0 else n - 1, dtype=BVH2_NODE)
+        leaves = np.empty(n, dtype=PRIMREF) if r.layout == 1 else None
+        keys = np.empty(n, dtype=np.uint32); vals = np.empty(n, dtype=np.uint32); scene = np.empty(1, dtype=AABB)
+        _check(lib().bvh_download(self._ctx.handle, C.byref(r), nodes.ctypes.data, leaves.ctypes.data if leaves is not None else None,
+                                  keys.ctypes.data, vals.ctypes.data, scene.ctypes.data), "bvh_download")
+        return {"nodes": nodes, "leaves": leaves, "sorted_keys": keys, "sorted_vals": vals, "scene": scene, "root": r.root, "layout": r.layout}
+
+    def sah_cost(self) -> float:
+        c = C.c_double()
+        _check(lib().bvh_sah_cost(self._ctx.handle, C.byref(self.result), C.byref(c)), "bvh_sah_cost")
+        self.m_cost = c.value
+        return c.value
+
+    def to_lbvh_layout(self) -> np.ndarray:
+        n = self.result.n_leaves
+        buf = self._ctx.alloc((2 * n - 1) * BVH2_NODE.itemsize)
+        _check(lib().bvh_to_lbvh_layout(self._ctx.handle, C.byref(self.result), buf.ptr), "bvh_to_lbvh_layout")
+        out = buf.download(BVH2_NODE, 2 * n - 1)
+        buf.free()
+        return out
+
+
+class TwoPassLbvh(_Builder):
+    ALGO = ALGO_TWOPASS
+
+
+class SinglePassLbvh(_Builder):
+    ALGO = ALGO_SINGLEPASS
+
+
+class PLOCNew(_Builder):
+    ALGO = ALGO_PLOCPP
+
+
+class HPLOC(_Builder):
+    ALGO = ALGO_HPLOC
+
+
+BUILDERS = {ALGO_TWOPASS: TwoPassLbvh, ALGO_SINGLEPASS: SinglePassLbvh, ALGO_PLOCPP: PLOCNew, ALGO_HPLOC: HPLOC}

@@ -1,0 +1,342 @@
+// api.hip — the C ABI of include/bvh_mi355x.h: context/arena management and the host orchestration of the build
+// (what X::build does in the reference: src/TwoPassLbvh.cpp:17-197, src/SinglePassLbvh.cpp:17-188,
+// src/PLOC++Bvh.cpp:16-196, src/Hploc.cpp:16-165 — minus RTC compilation, per-call allocation and debug read-backs).
+#include <hip/hip_runtime.h>
+#include <new>
+#include <cstring>
+#include "bvh_mi355x.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+using namespace bvh;
+
+struct bvh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    uint32_t cap = 0;                 // primitives the arena is sized for
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    // carved from the arena
+    void* tris = nullptr;             // Triangle[cap] staging for host inputs (allocated lazily, separate)
+    uint32_t tris_cap = 0;
+    bvh_aabb* boxes = nullptr;
+    float* scene = nullptr;
+    u32 *keys = nullptr, *skeys = nullptr, *svals = nullptr;
+    SortScratch sort{};
+    bvh2_node* nodes = nullptr;       // 2*cap
+    bvh_primref* leaves = nullptr;    // cap
+    u64* slots = nullptr;             // cap           (single-pass LBVH hand-off words)
+    u32* parent = nullptr;            // 2*cap         (two-pass parent pointers / HPLOC parentIdx)
+    u32* flags = nullptr;             // cap           (two-pass refit flags)
+    u32* cidx = nullptr;              // cap           (HPLOC nodeIndices0 / PLOC ids0)
+    PlocScratch ploc{};
+    u32* small = nullptr;             // 64 words: [0] root, [1] hploc node counter, [8..9] f64 SAH
+    hipEvent_t ev[6] = {};
+};
+
+namespace {
+
+inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
+#define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return -(int)_e; } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off = 0;
+    template <typename T> T* take(size_t count) { T* p = base ? reinterpret_cast<T*>(base + off) : nullptr; off += align_up(count * sizeof(T)); return p; }
+};
+
+void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
+    Carver k{base};
+    const size_t n = cap;
+    c->boxes = k.take<bvh_aabb>(n);
+    c->scene = k.take<float>(8);
+    c->keys = k.take<u32>(n); c->skeys = k.take<u32>(n); c->svals = k.take<u32>(n);
+    c->sort.tmp_keys = k.take<u32>(n); c->sort.tmp_vals = k.take<u32>(n);
+    c->sort.hist = k.take<u32>(SORT_MAX_PASSES * SORT_RADIX);
+    c->sort.status = k.take<u32>(sort_status_bytes(cap) / sizeof(u32));
+    c->sort.counters = k.take<u32>(SORT_MAX_PASSES);
+    c->nodes = k.take<bvh2_node>(2 * n);
+    c->leaves = k.take<bvh_primref>(n);
+    c->slots = k.take<u64>(n);
+    c->parent = k.take<u32>(2 * n);
+    c->flags = k.take<u32>(n);
+    c->cidx = k.take<u32>(n);
+    c->ploc.ids0 = c->cidx;
+    c->ploc.ids1 = k.take<u32>(n);
+    c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
+    c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);
+    c->small = k.take<u32>(64);
+    *total = k.off;
+}
+
+int ensure_capacity(bvh_ctx* c, uint32_t n) {
+    if (n <= c->cap) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->arena) { HIP_TRY(hipFree(c->arena)); c->arena = nullptr; c->cap = 0; }
+    size_t total = 0;
+    carve(c, nullptr, n, &total);
+    char* p = nullptr;
+    HIP_TRY(hipMalloc(&p, total));
+    c->arena = p; c->arena_bytes = total; c->cap = n;
+    carve(c, p, n, &total);
+    return 0;
+}
+
+int ensure_tris(bvh_ctx* c, uint32_t n) {
+    if (n <= c->tris_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->tris) { HIP_TRY(hipFree(c->tris)); c->tris = nullptr; c->tris_cap = 0; }
+    HIP_TRY(hipMalloc(&c->tris, (size_t)n * sizeof(bvh_triangle)));
+    c->tris_cap = n;
+    return 0;
+}
+
+struct Bind { int prev = -1; bool ok = true;
+    explicit Bind(int dev) { ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess); }
+    ~Bind() { int cur; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) hipSetDevice(prev); } };
+
+// PLOC++ iteration driver: batches of device-side iterations, one small read-back per batch (src/PLOC++Bvh.cpp:132-152
+// reads back after EVERY iteration).
+int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, const void* d_leaves, const PlocScratch& sc, uint32_t* iterations_out) {
+    u32 host_state[PLOC_STATE_WORDS];
+    int first = 0, parity = 0;
+    int batch = 48;
+    for (int guard = 0; guard < 4096; ++guard) {
+        if (first + batch > PLOC_MAX_ITERS) {
+            // restart the per-iteration bookkeeping with the current count (pathologically slow convergence only)
+            HIP_TRY(hipMemcpyAsync(host_state, sc.state, sizeof host_state, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const u32 count = host_state[first];
+            parity = (parity + first) & 1;
+            ploc_reset(c->stream, sc, n, count);
+            first = 0;
+        }
+        ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, first, batch, parity);
+        HIP_TRY(hipMemcpyAsync(host_state, sc.state, sizeof host_state, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const u32 count = host_state[first + batch];
+        if (count <= 1) { if (iterations_out) *iterations_out = host_state[2 * PLOC_MAX_ITERS + 1]; return 0; }
+        first += batch; batch = 16;
+    }
+    return BVH_E_INTERNAL;
+}
+
+// per-primitive algorithmic bytes of the whole pipeline (restated in DESIGN.md)
+uint64_t algorithmic_bytes(bvh_algo a, uint32_t n) {
+    static const uint64_t per_prim[4] = { 384, 420, 438, 386 };
+    return per_prim[(int)a] * (uint64_t)n;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* bvh_version(void) { return "bvh_mi355x 0.1 (gfx950)"; }
+
+int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
+    if (!out) return BVH_E_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return BVH_E_INVALID_ARG;
+    Bind b(device); if (!b.ok) return BVH_E_INVALID_ARG;
+    bvh_ctx* c = new (std::nothrow) bvh_ctx();
+    if (!c) return BVH_E_INTERNAL;
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return -(int)e; } c->own_stream = true; }
+    for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { delete c; return -(int)r; } }
+    *out = c;
+    return 0;
+}
+int bvh_ctx_create(int device, bvh_ctx** out) { return bvh_ctx_create_on_stream(device, nullptr, out); }
+
+void bvh_ctx_destroy(bvh_ctx* c) {
+    if (!c) return;
+    Bind b(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->arena) hipFree(c->arena);
+    if (c->tris) hipFree(c->tris);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bvh_ctx_reserve(bvh_ctx* c, uint32_t n) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return ensure_capacity(c, n); }
+int bvh_ctx_device(const bvh_ctx* c) { return c ? c->device : -1; }
+void* bvh_ctx_stream(const bvh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int bvh_ctx_set_profiling(bvh_ctx* c, int enabled) { if (!c) return BVH_E_INVALID_ARG; c->profiling = enabled != 0; return 0; }
+int bvh_ctx_synchronize(bvh_ctx* c) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return herr(hipStreamSynchronize(c->stream)); }
+
+int bvh_stage_extents(bvh_ctx* c, const void* d_tris, uint32_t n, void* d_prim_aabbs, void* d_scene_extent) {
+    if (!c || !d_tris || !d_prim_aabbs || !d_scene_extent || n == 0) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    launch_extents(c->stream, d_tris, n, d_prim_aabbs, d_scene_extent);
+    return herr(hipGetLastError());
+}
+
+int bvh_stage_morton(bvh_ctx* c, const void* d_prim_aabbs, uint32_t n, const void* d_scene_extent, uint32_t* d_keys, uint32_t* d_vals) {
+    if (!c || !d_prim_aabbs || !d_scene_extent || !d_keys || n == 0) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    launch_morton(c->stream, d_prim_aabbs, n, d_scene_extent, d_keys, d_vals, nullptr, 0, 0);
+    return herr(hipGetLastError());
+}
+
+int bvh_sort_pairs(bvh_ctx* c, const uint32_t* d_keys_in, const uint32_t* d_vals_in, uint32_t n, uint32_t* d_keys_out,
+                   uint32_t* d_vals_out, int start_bit, int end_bit) {
+    if (!c || !d_keys_in || !d_keys_out || !d_vals_out || n == 0 || start_bit < 0 || end_bit > 32 || start_bit > end_bit) return BVH_E_INVALID_ARG;
+    if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    sort_prepare(c->stream, c->sort, n);
+    sort_pairs(c->stream, c->sort, d_keys_in, d_vals_in, n, d_keys_out, d_vals_out, start_bit, end_bit, false);
+    return herr(hipGetLastError());
+}
+
+int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted_keys, const uint32_t* d_sorted_vals,
+                         uint32_t n, void* d_nodes, uint32_t* root_out) {
+    if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, c->slots, c->small);
+    HIP_TRY(hipGetLastError());
+    if (root_out) { HIP_TRY(hipMemcpyAsync(root_out, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    return 0;
+}
+
+int bvh_emit_lbvh_two(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted_keys, const uint32_t* d_sorted_vals,
+                      uint32_t n, void* d_nodes) {
+    if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, c->parent, c->flags);
+    return herr(hipGetLastError());
+}
+
+int bvh_emit_ploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted_vals, uint32_t n, void* d_nodes, void* d_leaves,
+                  uint32_t* iterations_out) {
+    if (!c || !d_prim_aabbs || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    ploc_begin(c->stream, c->ploc, d_prim_aabbs, d_sorted_vals, n, d_leaves);
+    HIP_TRY(hipGetLastError());
+    return run_ploc(c, n, d_nodes, d_leaves, c->ploc, iterations_out);
+}
+
+int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted_keys, const uint32_t* d_sorted_vals, uint32_t n,
+                   void* d_nodes, void* d_leaves) {
+    if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    launch_hploc(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->cidx, c->parent, c->small + 1);
+    return herr(hipGetLastError());
+}
+
+int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_on_device, bvh_result* out, bvh_timings* tm) {
+    if (!c || !tris || !out || n < 2 || (int)algo < 0 || (int)algo > 3) return BVH_E_INVALID_ARG;
+    if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    const void* d_tris = tris;
+    if (!tris_on_device) {   // H2D copy of the input, outside the timers (src/TwoPassLbvh.cpp:19-20)
+        r = ensure_tris(c, n); if (r) return r;
+        HIP_TRY(hipMemcpyAsync(c->tris, tris, (size_t)n * sizeof(bvh_triangle), hipMemcpyHostToDevice, c->stream));
+        d_tris = c->tris;
+    }
+    hipStream_t s = c->stream;
+    const bool prof = c->profiling;
+    uint32_t ploc_iters = 0;
+    if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
+    // E: CalculateSceneExtents (token CalculateCentroidExtentsTime).  The sort's bookkeeping is cleared here so that the
+    // Morton kernel can accumulate the digit histograms.
+    sort_prepare(s, c->sort, n);
+    launch_extents(s, d_tris, n, c->boxes, c->scene);
+    if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
+    // M: CalculateMortonCodes (token CalculateMortonCodesTime); values are implicit (value i = i), produced by sort pass 0
+    const int end_bit = 30;
+    launch_morton(s, c->boxes, n, c->scene, c->keys, nullptr, c->sort.hist, SORT_BITS, sort_passes(0, end_bit));
+    if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
+    // S: radix sort (token SortingTime).  Morton codes have 30 significant bits.
+    sort_pairs(s, c->sort, c->keys, nullptr, n, c->skeys, c->svals, 0, end_bit, true);
+    if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
+    // B: hierarchy emit (token BvhBuildTime; SetupClusters is booked here, not under Morton as the reference does)
+    out->d_leaves = nullptr; out->layout = 0; out->root = 0;
+    switch (algo) {
+        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->slots, c->small); break;
+        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->parent, c->flags); break;
+        case BVH_HPLOC:           launch_hploc(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->cidx, c->parent, c->small + 1);
+                                  out->d_leaves = c->leaves; out->layout = 1; break;
+        case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);
+                                  r = run_ploc(c, n, c->nodes, c->leaves, c->ploc, &ploc_iters); if (r) return r;
+                                  out->d_leaves = c->leaves; out->layout = 1; break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
+    if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
+        HIP_TRY(hipMemcpyAsync(&out->root, c->small, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = c->scene;
+    out->d_sorted_keys = c->skeys; out->d_sorted_vals = c->svals;
+    out->n_internal = n - 1; out->n_leaves = n;
+    if (tm) {
+        std::memset(tm, 0, sizeof *tm);
+        tm->bytes_algorithmic = algorithmic_bytes(algo, n);
+        tm->ploc_iterations = ploc_iters;
+        if (prof) {
+            HIP_TRY(hipEventSynchronize(c->ev[4]));
+            HIP_TRY(hipEventElapsedTime(&tm->ms_extents, c->ev[0], c->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&tm->ms_morton, c->ev[1], c->ev[2]));
+            HIP_TRY(hipEventElapsedTime(&tm->ms_sort, c->ev[2], c->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&tm->ms_build, c->ev[3], c->ev[4]));
+            tm->ms_total = tm->ms_extents + tm->ms_morton + tm->ms_sort + tm->ms_build;
+        }
+    }
+    return 0;
+}
+
+int bvh_to_lbvh_layout(bvh_ctx* c, const bvh_result* in, void* d_out) {
+    if (!c || !in || !d_out || !in->d_nodes) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    if (in->layout == 0) { HIP_TRY(hipMemcpyAsync(d_out, in->d_nodes, (size_t)(2 * in->n_leaves - 1) * sizeof(bvh2_node), hipMemcpyDeviceToDevice, c->stream)); return 0; }
+    launch_to_lbvh_layout(c->stream, in->d_nodes, in->d_leaves, in->n_leaves, d_out);
+    return herr(hipGetLastError());
+}
+
+int bvh_sah_cost(bvh_ctx* c, const bvh_result* in, double* cost_out) {
+    if (!c || !in || !cost_out || !in->d_nodes) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    double* d = reinterpret_cast<double*>(c->small + 8);
+    launch_sah_cost(c->stream, in->d_nodes, in->d_leaves, in->root, in->n_leaves, (int)in->layout, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(cost_out, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return herr(hipStreamSynchronize(c->stream));
+}
+
+int bvh_download(bvh_ctx* c, const bvh_result* in, void* h_nodes, void* h_leaves, uint32_t* h_sorted_keys, uint32_t* h_sorted_vals, void* h_scene) {
+    if (!c || !in) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    const size_t n = in->n_leaves;
+    const size_t node_count = in->layout == 0 ? 2 * n - 1 : n - 1;
+    if (h_nodes) HIP_TRY(hipMemcpyAsync(h_nodes, in->d_nodes, node_count * sizeof(bvh2_node), hipMemcpyDeviceToHost, c->stream));
+    if (h_leaves && in->d_leaves) HIP_TRY(hipMemcpyAsync(h_leaves, in->d_leaves, n * sizeof(bvh_primref), hipMemcpyDeviceToHost, c->stream));
+    if (h_sorted_keys) HIP_TRY(hipMemcpyAsync(h_sorted_keys, in->d_sorted_keys, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_sorted_vals) HIP_TRY(hipMemcpyAsync(h_sorted_vals, in->d_sorted_vals, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_scene) HIP_TRY(hipMemcpyAsync(h_scene, in->d_scene_extent, sizeof(bvh_aabb), hipMemcpyDeviceToHost, c->stream));
+    return herr(hipStreamSynchronize(c->stream));
+}
+
+// plain device memory helpers so that non-HIP hosts (ctypes, cgo ...) can stage buffers without linking the HIP runtime
+int bvh_dev_alloc(bvh_ctx* c, uint64_t bytes, void** out) { if (!c || !out) return BVH_E_INVALID_ARG; Bind b(c->device); return herr(hipMalloc(out, bytes)); }
+int bvh_dev_free(bvh_ctx* c, void* p) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return herr(hipFree(p)); }
+int bvh_dev_upload(bvh_ctx* c, void* d_dst, const void* h_src, uint64_t bytes) {
+    if (!c) return BVH_E_INVALID_ARG; Bind b(c->device);
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream)); return herr(hipStreamSynchronize(c->stream)); }
+int bvh_dev_download(bvh_ctx* c, void* h_dst, const void* d_src, uint64_t bytes) {
+    if (!c) return BVH_E_INVALID_ARG; Bind b(c->device);
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream)); return herr(hipStreamSynchronize(c->stream)); }
+
+} // extern "C"

@@ -1,0 +1,72 @@
+// common.hpp — device helpers shared by the gfx950 kernels of the BVH build path.
+// Wave width is hard-coded to 64 (CDNA4).  Compiled with -ffp-contract=off: the area expression and the Morton
+// quantisation must round exactly like the CPU oracle (ties on area bit patterns decide PLOC/HPLOC merges).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bvh/types.h"
+
+namespace bvh {
+
+using u32 = uint32_t;
+using u64 = uint64_t;
+constexpr u32 INV = BVH_INVALID;
+constexpr float FMAX = BVH_FLT_MAX;
+constexpr int WAVE = 64;
+
+struct Box { float lx, ly, lz, hx, hy, hz; };   // = bvh_aabb / reference Aabb (24 B)
+
+__device__ __forceinline__ Box box_empty() { return { FMAX, FMAX, FMAX, -FMAX, -FMAX, -FMAX }; }   // Aabb::reset, src/Common.h:327-331
+__device__ __forceinline__ Box box_union(const Box& a, const Box& b) {                              // Aabb::grow / merge, :333-338,:456-459
+    return { fminf(a.lx, b.lx), fminf(a.ly, b.ly), fminf(a.lz, b.lz), fmaxf(a.hx, b.hx), fmaxf(a.hy, b.hy), fmaxf(a.hz, b.hz) };
+}
+__device__ __forceinline__ float box_area(const Box& b) {                                           // Aabb::area, :361-365 (no FMA)
+    const float ex = b.hx - b.lx, ey = b.hy - b.ly, ez = b.hz - b.lz;
+    return 2 * (ex * ey + ex * ez + ey * ez);
+}
+
+// ---- agent-scope (device-wide, cross-XCD) accesses -------------------------------------------------------------
+// MI355X has 8 XCDs with private L2s and per-CU L1s that other CUs' stores never refresh.  Data handed between
+// workgroups inside one launch therefore travels as relaxed agent-scope atomics (global_load/store ... sc1: L1 bypass,
+// write-through) and the hand-off word itself is an agent-scope atomic RMW issued after the producer drained its
+// stores (s_waitcnt vmcnt(0)).  See DESIGN.md "Inter-workgroup hand-off".
+__device__ __forceinline__ u32  ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64  ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+
+__device__ __forceinline__ u64 pack2(float a, float b) { return (u64)__float_as_uint(a) | ((u64)__float_as_uint(b) << 32); }
+__device__ __forceinline__ float lo_f(u64 v) { return __uint_as_float((u32)v); }
+__device__ __forceinline__ float hi_f(u64 v) { return __uint_as_float((u32)(v >> 32)); }
+
+// Bvh2Node (32 B, 32-B aligned) = 4 x u64: {left,right} {lx,ly} {lz,hx} {hy,hz}
+__device__ __forceinline__ void node_store_agent(bvh2_node* n, u32 left, u32 right, const Box& b) {
+    u64* q = reinterpret_cast<u64*>(n);
+    st_agent(q + 0, (u64)left | ((u64)right << 32));
+    st_agent(q + 1, pack2(b.lx, b.ly));
+    st_agent(q + 2, pack2(b.lz, b.hx));
+    st_agent(q + 3, pack2(b.hy, b.hz));
+}
+__device__ __forceinline__ Box node_box_agent(const bvh2_node* n) {
+    const u64* q = reinterpret_cast<const u64*>(n);
+    const u64 a = ld_agent(q + 1), b = ld_agent(q + 2), c = ld_agent(q + 3);
+    return { lo_f(a), hi_f(a), lo_f(b), hi_f(b), lo_f(c), hi_f(c) };
+}
+__device__ __forceinline__ Box box_load(const bvh_aabb* p) {   // plain load (data from an earlier kernel)
+    const float* f = reinterpret_cast<const float*>(p);
+    return { f[0], f[1], f[2], f[3], f[4], f[5] };
+}
+__device__ __forceinline__ void box_store(bvh_aabb* p, const Box& b) {
+    float* f = reinterpret_cast<float*>(p);
+    f[0] = b.lx; f[1] = b.ly; f[2] = b.lz; f[3] = b.hx; f[4] = b.hy; f[5] = b.hz;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// 64-bit augmented key of sorted position i (Morton key in the high word, position in the low word)
+__device__ __forceinline__ u64 aug_key(const u32* __restrict__ keys, u32 i) { return ((u64)keys[i] << 32) | i; }
+
+} // namespace bvh

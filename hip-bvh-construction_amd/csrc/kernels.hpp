@@ -1,0 +1,66 @@
+// kernels.hpp — host-side launch interface of the gfx950 kernels (internal; the public boundary is include/bvh_mi355x.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bvh {
+
+constexpr int EM_BLOCK = 256;
+
+// ---- stage E / M (stage_em.hip)
+void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes, void* d_scene);
+void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint32_t* d_keys, uint32_t* d_vals,
+                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes);
+
+// ---- stage S (sort.hip): one-sweep LSD radix sort, SORT_BITS-bit digits
+constexpr int SORT_BITS = 8;
+constexpr int SORT_RADIX = 1 << SORT_BITS;
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_IPT = 16;                                  // keys per thread
+constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup
+constexpr int SORT_MAX_PASSES = 4;
+struct SortScratch {
+    uint32_t* tmp_keys;      // u32[n]
+    uint32_t* tmp_vals;      // u32[n]
+    uint32_t* hist;          // u32[SORT_MAX_PASSES * SORT_RADIX]   (zeroed by sort_prepare)
+    uint32_t* status;        // u32[SORT_MAX_PASSES * tiles * SORT_RADIX] (zeroed by sort_prepare)
+    uint32_t* counters;      // u32[SORT_MAX_PASSES]                 (zeroed by sort_prepare)
+};
+inline uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+inline int sort_passes(int start_bit, int end_bit) { return (end_bit - start_bit + SORT_BITS - 1) / SORT_BITS; }
+size_t sort_status_bytes(uint32_t n);
+// zero hist/status/counters (one memset; must precede the histogram producer)
+void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n);
+// hist_ready: sc.hist already holds the per-pass digit counts (fused into the Morton kernel); else a histogram kernel runs.
+void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready);
+
+// ---- stage B (lbvh.hip, hploc.hip, ploc.hip)
+void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                        void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root);
+void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                     void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
+void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                  void* d_nodes, void* d_leaves, uint32_t* d_cluster_idx /*u32[n]*/, uint32_t* d_parent /*u32[n]*/,
+                  uint32_t* d_counter /*u32[1]*/);
+struct PlocScratch {
+    uint32_t* ids0;          // u32[n]
+    uint32_t* ids1;          // u32[n]
+    uint64_t* status;        // u64[PLOC_MAX_ITERS * chunks]
+    uint32_t* state;         // u32[PLOC_STATE_WORDS]
+};
+constexpr int PLOC_CHUNK = 1024;
+constexpr int PLOC_MAX_ITERS = 96;
+constexpr int PLOC_STATE_WORDS = 2 * PLOC_MAX_ITERS + 4;     // counts[MAX+1] | tickets[MAX] | iterations done
+inline uint32_t ploc_chunks(uint32_t n) { return (n + PLOC_CHUNK - 1) / PLOC_CHUNK; }
+void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,
+                           uint32_t* d_cluster_idx, uint32_t* d_parent /*may be null*/);
+void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves);
+void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count);
+void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity);
+
+// ---- helpers (misc.hip)
+void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out);
+void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t root, uint32_t n, int layout, double* d_out /*[1], zeroed inside*/);
+
+} // namespace bvh

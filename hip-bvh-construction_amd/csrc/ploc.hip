@@ -1,0 +1,228 @@
+// ploc.hip — stage B for PLOC++ on gfx950.
+//
+// Replaces SetupClusters + Ploc + SinglePassPloc and the host iteration loop of the reference (src/Ploc++Kernel.h:39-55,
+// :211-362, :98-209; src/PLOC++Bvh.cpp:82-152).  Output: Bvh2Node[n-1] (root = node 0) + PrimRef[n] leaves.
+//
+// One iteration = for every cluster of the Morton-ordered list find the nearest neighbour within +-8 list positions under
+// the {area-of-union bits, list position} order, merge mutual pairs (lower position owns the new node), compact the list
+// in order.  The reference evaluates this per 1024-cluster chunk with a 16-entry halo on both sides (:232-270), which is
+// what this kernel does too; chunks are chained with decoupled look-back on one 64-bit status word {flag, merges, kept}
+// instead of the reference's serial spin chain over blocks (:341-347), and the new node index is C-2-(rank of the merge in
+// list order) — one of the arrival orders the reference's global atomicAdd (:311) can produce, here deterministic.
+// The iteration loop stays on the device: iteration k reads the cluster count from state[k], writes state[k+1]; the host
+// enqueues a batch of launches without reading anything back (the reference syncs D2H every iteration, src/PLOC++Bvh.cpp:150).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace bvh {
+
+constexpr int PL_BLOCK = 256;
+constexpr int PL_RADIUS = 8;                   // PlocRadius, src/Common.h:595
+constexpr int PL_HALO = 2 * PL_RADIUS;         // :219-221
+constexpr int PL_SPAN = PLOC_CHUNK + 2 * PL_HALO;
+constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
+constexpr u64 PS_LOCAL = 1ull << 62, PS_INCL = 2ull << 62;
+
+struct PlocLds {
+    float lx[PL_SPAN], ly[PL_SPAN], lz[PL_SPAN], hx[PL_SPAN], hy[PL_SPAN], hz[PL_SPAN];
+    u32 id[PL_SPAN];
+    u32 nn[PL_SPAN];        // nearest neighbour, as an index into the span arrays
+    u32 wsum[PL_BLOCK / WAVE];
+    u32 bcast[4];
+};
+
+__device__ __forceinline__ Box lds_box(const PlocLds& s, int k) { return { s.lx[k], s.ly[k], s.lz[k], s.hx[k], s.hy[k], s.hz[k] }; }
+__device__ __forceinline__ void lds_set(PlocLds& s, int k, u32 id, const Box& b) {
+    s.id[k] = id; s.lx[k] = b.lx; s.ly[k] = b.ly; s.lz[k] = b.lz; s.hx[k] = b.hx; s.hy[k] = b.hy; s.hz[k] = b.hz;
+}
+__device__ __forceinline__ Box cluster_box(u32 id, u32 ni, const bvh_primref* __restrict__ leaves, const bvh2_node* __restrict__ nodes) {
+    return id >= ni ? box_load(&leaves[id - ni].aabb) : box_load(&nodes[id].aabb);   // :237-241 (nodes of earlier launches)
+}
+
+// nearest neighbour of span entry k among valid entries [lo, hi) within +-8, key {area bits, position}
+__device__ __forceinline__ u32 nearest(const PlocLds& s, int k, int lo, int hi) {
+    const Box b = lds_box(s, k);
+    u64 best = ~0ull;
+#pragma unroll
+    for (int r = 1; r <= PL_RADIUS; ++r) {
+        const int a = k - r, c = k + r;
+        if (a >= lo) { const u64 key = ((u64)__float_as_uint(box_area(box_union(lds_box(s, a), b))) << 32) | (u32)a; best = key < best ? key : best; }
+        if (c < hi)  { const u64 key = ((u64)__float_as_uint(box_area(box_union(lds_box(s, c), b))) << 32) | (u32)c; best = key < best ? key : best; }
+    }
+    return (u32)best;
+}
+
+// block-wide exclusive scan of a packed {merges<<16 | kept} per-thread count; returns exclusive prefix, total via *total
+__device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    u32 inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const u32 t = (u32)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
+    __syncthreads();                               // protects wsum reuse
+    if (lane == WAVE - 1) s.wsum[wave] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PL_BLOCK / WAVE; ++w) { const u32 c = s.wsum[w]; if (w < wave) base += c; tot += c; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
+__global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const u32* __restrict__ ids_in, u32* __restrict__ ids_out,
+                                                        bvh2_node* __restrict__ nodes, const bvh_primref* __restrict__ leaves,
+                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni) {
+    __shared__ PlocLds s;
+    const u32 C = counts[0];
+    if (C <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = C; return; }
+    const int tid = threadIdx.x;
+
+    if (C < (u32)PLOC_CHUNK) {
+        // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
+        if (blockIdx.x != 0) return;
+        for (int k = tid; k < (int)C; k += PL_BLOCK) { const u32 id = ids_in[k]; lds_set(s, k, id, cluster_box(id, ni, leaves, nodes)); }
+        __syncthreads();
+        u32 c = C;
+        while (c > 1) {
+            for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = nearest(s, k, 0, (int)c);   // :131-148, range clipped to [0,c)
+            __syncthreads();
+            // each thread owns PL_CPT consecutive list positions
+            u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
+            u32 packed = 0;
+#pragma unroll
+            for (int q = 0; q < PL_CPT; ++q) {
+                const int k = tid * PL_CPT + q;
+                mrg[q] = false; keep[q] = false; cid[q] = INV; pid[q] = INV; cb[q] = box_empty();
+                if (k < (int)c) {
+                    const u32 nb = s.nn[k];
+                    const bool mutual = s.nn[nb] == (u32)k;
+                    mrg[q] = mutual && (u32)k < nb; keep[q] = !mutual || mrg[q];
+                    cid[q] = s.id[k]; cb[q] = lds_box(s, k);
+                    if (mrg[q]) { pid[q] = s.id[nb]; cb[q] = box_union(cb[q], lds_box(s, (int)nb)); }
+                    packed += ((u32)mrg[q] << 16) + (u32)keep[q];
+                }
+            }
+            u32 tot; u32 ex = block_scan(s, packed, &tot);     // (block_scan's barriers also order the reads above)
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PL_CPT; ++q) {
+                if (keep[q]) {
+                    u32 id = cid[q];
+                    if (mrg[q]) {
+                        id = c - 2 - (ex >> 16);                  // :168
+                        bvh2_node* nd = nodes + id;
+                        nd->left = cid[q]; nd->right = pid[q]; box_store(&nd->aabb, cb[q]);
+                    }
+                    lds_set(s, (int)(ex & 0xFFFFu), id, cb[q]);
+                }
+                ex += ((u32)mrg[q] << 16) + (u32)keep[q];
+            }
+            __syncthreads();
+            c = tot & 0xFFFFu;
+        }
+        if (tid == 0) { counts[1] = 1; atomicAdd(iters_done, 1u); }
+        return;
+    }
+
+    // ---- one global iteration (Ploc :211-362), persistent over chunk tickets
+    const u32 chunks = (C + PLOC_CHUNK - 1) / PLOC_CHUNK;
+    while (true) {
+        __syncthreads();
+        if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
+        __syncthreads();
+        const u32 chunk = s.bcast[0];
+        if (chunk >= chunks) break;
+        const long long o = (long long)chunk * PLOC_CHUNK;
+        // span entry k <-> list position o - HALO + k   (:232-249)
+        for (int k = tid; k < PL_SPAN; k += PL_BLOCK) {
+            const long long gpos = o - PL_HALO + k;
+            if (gpos >= 0 && gpos < (long long)C) { const u32 id = ids_in[gpos]; lds_set(s, k, id, cluster_box(id, ni, leaves, nodes)); }
+            else s.id[k] = INV;
+        }
+        __syncthreads();
+        const int lo = (int)(o - PL_HALO < 0 ? PL_HALO - o : 0);                                   // first valid span entry
+        const int hi = (int)((long long)C - (o - PL_HALO) < PL_SPAN ? (long long)C - (o - PL_HALO) : PL_SPAN);   // one past the last valid
+        // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270)
+        for (int k = PL_HALO - PL_RADIUS + tid; k < PL_HALO + PLOC_CHUNK + PL_RADIUS; k += PL_BLOCK)
+            if (k >= lo && k < hi) s.nn[k] = nearest(s, k, lo, hi);
+        __syncthreads();
+        u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
+        u32 packed = 0;
+#pragma unroll
+        for (int q = 0; q < PL_CPT; ++q) {
+            const int k = PL_HALO + tid * PL_CPT + q;
+            mrg[q] = false; keep[q] = false; cid[q] = INV; pid[q] = INV; cb[q] = box_empty();
+            if (k < hi) {                                                                            // :274 gIdx < nClusters
+                const u32 nb = s.nn[k];
+                const bool mutual = s.nn[nb] == (u32)k;                                              // :276-287
+                mrg[q] = mutual && (u32)k < nb; keep[q] = !mutual || mrg[q];
+                cid[q] = s.id[k];
+                if (mrg[q]) { pid[q] = s.id[nb]; cb[q] = box_union(lds_box(s, k), lds_box(s, (int)nb)); }
+                packed += ((u32)mrg[q] << 16) + (u32)keep[q];
+            }
+        }
+        u32 tot; u32 ex = block_scan(s, packed, &tot);
+        // chain the chunk totals: status word {flag:2, merges:31, kept:31}
+        if (tid == 0) {
+            const u64 mine = ((u64)(tot >> 16) << 31) | (u64)(tot & 0xFFFFu);
+            u64 excl = 0;
+            if (chunk == 0) __hip_atomic_store(status + chunk, PS_INCL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else {
+                __hip_atomic_store(status + chunk, PS_LOCAL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long long prev = (long long)chunk - 1;
+                while (true) {
+                    const u64 st = __hip_atomic_load(status + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 flag = st >> 62;
+                    if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+                    excl += st & ((1ull << 62) - 1ull);
+                    if (flag == 2) break;
+                    --prev;
+                }
+                __hip_atomic_store(status + chunk, PS_INCL | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s.bcast[1] = (u32)(excl >> 31); s.bcast[2] = (u32)(excl & 0x7FFFFFFFull);
+            if (chunk == chunks - 1) { counts[1] = C - ((u32)(excl >> 31) + (tot >> 16)); atomicAdd(iters_done, 1u); }   // src/PLOC++Bvh.cpp:150
+        }
+        __syncthreads();
+        const u32 m_ex = s.bcast[1], k_ex = s.bcast[2];
+#pragma unroll
+        for (int q = 0; q < PL_CPT; ++q) {
+            if (keep[q]) {
+                u32 id = cid[q];
+                if (mrg[q]) {
+                    id = C - 2 - (m_ex + (ex >> 16));                                                // :311
+                    bvh2_node* nd = nodes + id;
+                    nd->left = cid[q]; nd->right = pid[q]; box_store(&nd->aabb, cb[q]);
+                }
+                ids_out[k_ex + (ex & 0xFFFFu)] = id;                                                 // :355-361
+            }
+            ex += ((u32)mrg[q] << 16) + (u32)keep[q];
+        }
+    }
+}
+
+__global__ void k_ploc_init(u32* state, u32 n) { if (threadIdx.x == 0) state[0] = n; }
+
+// state words: counts[0..MAX_ITERS] | tickets[0..MAX_ITERS) | iterations done
+void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves) {
+    launch_setup_clusters(s, d_boxes, d_svals, n, d_leaves, sc.ids0, nullptr);
+    ploc_reset(s, sc, n, n);
+}
+void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count) {
+    hipMemsetAsync(sc.state, 0, PLOC_STATE_WORDS * sizeof(u32), s);
+    hipMemsetAsync(sc.status, 0, (size_t)PLOC_MAX_ITERS * ploc_chunks(n) * sizeof(u64), s);
+    hipLaunchKernelGGL(k_ploc_init, dim3(1), dim3(64), 0, s, sc.state, count);
+}
+// enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads
+void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity) {
+    const u32 chunks = ploc_chunks(n);
+    const u32 grid = chunks < 1024u ? chunks : 1024u;
+    u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
+    for (int k = first; k < first + count; ++k) {
+        const bool even = ((k + parity) & 1) == 0;
+        hipLaunchKernelGGL(k_ploc_iter, dim3(grid), dim3(PL_BLOCK), 0, s, even ? sc.ids0 : sc.ids1, even ? sc.ids1 : sc.ids0,
+                           (bvh2_node*)d_nodes, (const bvh_primref*)d_leaves, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
+    }
+}
+
+} // namespace bvh

@@ -1,0 +1,211 @@
+// sort.hip — stage S: one-sweep LSD radix sort of (u32 key, u32 value) pairs for gfx950.
+//
+// Replaces Oro::RadixSort::sort(KeyValueSoA src, KeyValueSoA dst, n, startBit, endBit, stream) — the reference's only
+// use of the (un-vendored) Orochi library on this path; call sites src/TwoPassLbvh.cpp:71-89, src/SinglePassLbvh.cpp:72-90,
+// src/PLOC++Bvh.cpp:62-80, src/Hploc.cpp:63-81.  Contract: stable ascending order on key bits [start,end).
+//
+// Design (CDNA4):
+//  * 8-bit digits; every pass reads each pair once and writes it once (16 B per pair per pass) — the digit histograms of
+//    ALL passes are produced up front (fused into the Morton kernel, or by k_hist for the stand-alone entry point), so no
+//    pass re-reads keys to count.
+//  * one workgroup (4 wave64) sorts a tile of 4096 pairs: per-wave ranking by ballot "match-any" (8 ballots per key, no
+//    LDS atomics, stable by construction), per-wave digit counters in LDS, a cross-wave scan, then the tile's digit totals
+//    are chained to earlier tiles by decoupled look-back on 32-bit status words {flag:2, count:30}.  Status words are
+//    relaxed agent-scope atomics: the value is its own flag, so no fence is needed across XCDs.
+//  * tile ids come from an atomic ticket, so a tile only ever waits on tiles that are already running.
+//  * pairs are staged through LDS in their tile-sorted order so that global writes are runs of consecutive addresses.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace bvh {
+
+static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit");
+constexpr u32 ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
+
+// stand-alone histogram (all passes in one read of the keys)
+__global__ __launch_bounds__(SORT_BLOCK) void k_hist(const u32* __restrict__ keys, u32 n, int start_bit, int end_bit, int passes,
+                                                     u32* __restrict__ hist) {
+    __shared__ u32 s_hist[SORT_MAX_PASSES * SORT_RADIX];
+    for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) s_hist[i] = 0;
+    __syncthreads();
+    const u32 stride = gridDim.x * SORT_BLOCK;
+    for (u32 i = blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += stride) {
+        const u32 k = keys[i];
+        for (int p = 0; p < passes; ++p) {
+            const int sh = start_bit + p * SORT_BITS;
+            const int w = min(SORT_BITS, end_bit - sh);
+            atomicAdd(&s_hist[p * SORT_RADIX + ((k >> sh) & ((1u << w) - 1u))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&hist[i], c); }
+}
+
+// per-pass exclusive scan of the digit counts, in place.  grid = passes, block = SORT_RADIX
+__global__ __launch_bounds__(SORT_RADIX) void k_scan_hist(u32* __restrict__ hist) {
+    __shared__ u32 s[SORT_RADIX];
+    u32* h = hist + blockIdx.x * SORT_RADIX;
+    const u32 v = h[threadIdx.x];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < SORT_RADIX; off <<= 1) {
+        const u32 t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    h[threadIdx.x] = s[threadIdx.x] - v;
+}
+
+template <bool IOTA>
+__global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                         u32* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
+                                                         int shift, u32 digit_mask, const u32* __restrict__ ghist,
+                                                         u32* status, u32* tile_counter) {
+    constexpr int NW = SORT_BLOCK / WAVE;
+    __shared__ u32 s_whist[NW][SORT_RADIX];
+    __shared__ u32 s_binoff[SORT_RADIX];
+    __shared__ u32 s_gbase[SORT_RADIX];
+    __shared__ u32 s_keys[SORT_TILE];
+    __shared__ u32 s_vals[SORT_TILE];
+    __shared__ u32 s_wsum[NW];
+    __shared__ u32 s_tile;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
+    __syncthreads();
+    const u32 tile = s_tile;
+    const u32 base = tile * (u32)SORT_TILE;
+    const u32 valid = min((u32)SORT_TILE, n - base);
+
+    // ---- load (wave-striped: wave w owns a contiguous 64*IPT span, item i is a coalesced 256-B row of it)
+    u32 key[SORT_IPT], val[SORT_IPT], pos[SORT_IPT];
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; ++i) {
+        const u32 local = (u32)(wave * WAVE * SORT_IPT + i * WAVE + lane);
+        const bool ok = local < valid;
+        key[i] = ok ? keys_in[base + local] : 0xFFFFFFFFu;
+        val[i] = IOTA ? (base + local) : (ok ? vals_in[base + local] : 0u);
+    }
+    // ---- rank inside the wave: lanes holding the same digit form a group (8 ballots); the group's lowest lane bumps the
+    // wave's LDS counter for that digit, every member gets counter-before + its index inside the group.  Program order
+    // (item-major, then lane) is exactly memory order inside the wave's span => stable.
+    const u64 lt = lanemask_lt();
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; ++i) {
+        const u32 d = (key[i] >> shift) & digit_mask;
+        u64 grp = ~0ull;
+#pragma unroll
+        for (int b = 0; b < SORT_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            grp &= bit ? bal : ~bal;
+        }
+        const u32 below = (u32)__popcll(grp & lt);
+        const int leader = __ffsll((unsigned long long)grp) - 1;
+        u32 before = 0;
+        if (below == 0) { before = s_whist[wave][d]; s_whist[wave][d] = before + (u32)__popcll(grp); }
+        pos[i] = (u32)__shfl((int)before, leader) + below;
+    }
+    __syncthreads();
+
+    // ---- digit `tid`: totals over the 4 waves, exclusive wave offsets back into s_whist, publish the tile aggregate
+    u32 total;
+    {
+        u32 run = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const u32 c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
+        total = run;
+        if ((u32)tid == digit_mask) total -= (u32)SORT_TILE - valid;     // padding keys (all ones) carry the top digit; they are not data
+        st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | total);
+    }
+    // ---- exclusive scan of the 256 digit totals (wave scan + LDS hop) -> s_binoff
+    {
+        u32 inc = total;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) { const u32 t = (u32)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
+        if (lane == WAVE - 1) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 wbase = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) if (w < wave) wbase += s_wsum[w];
+        s_binoff[tid] = wbase + inc - total;
+    }
+    // ---- decoupled look-back for digit `tid`
+    {
+        u32 excl = 0;
+        if (tile > 0) {
+            int prev = (int)tile - 1;
+            while (true) {
+                const u32 st = ld_agent(&status[(size_t)prev * SORT_RADIX + tid]);
+                const u32 flag = st >> 30;
+                if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+                excl += st & ST_MASK;
+                if (flag == 2) break;
+                --prev;
+            }
+            st_agent(&status[(size_t)tile * SORT_RADIX + tid], ST_INCL | (excl + total));
+        }
+        s_gbase[tid] = ghist[tid] + excl - s_binoff[tid];
+    }
+    __syncthreads();
+
+    // ---- tile-local sort through LDS
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; ++i) {
+        const u32 d = (key[i] >> shift) & digit_mask;
+        const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
+        s_keys[p] = key[i]; s_vals[p] = val[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_IPT; ++k) {
+        const u32 p = (u32)(k * SORT_BLOCK + tid);
+        if (p < valid) {
+            const u32 kk = s_keys[p];
+            const u32 dst = s_gbase[(kk >> shift) & digit_mask] + p;
+            keys_out[dst] = kk; vals_out[dst] = s_vals[p];
+        }
+    }
+}
+
+size_t sort_status_bytes(uint32_t n) { return (size_t)SORT_MAX_PASSES * sort_tiles(n) * SORT_RADIX * sizeof(u32); }
+
+void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n) {
+    hipMemsetAsync(sc.hist, 0, SORT_MAX_PASSES * SORT_RADIX * sizeof(u32), s);
+    hipMemsetAsync(sc.status, 0, sort_status_bytes(n), s);
+    hipMemsetAsync(sc.counters, 0, SORT_MAX_PASSES * sizeof(u32), s);
+}
+
+void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
+    const int passes = sort_passes(start_bit, end_bit);
+    if (passes <= 0) {   // nothing to sort on: identity permutation
+        hipMemcpyAsync(keys_out, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        if (vals_in) hipMemcpyAsync(vals_out, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        return;
+    }
+    const u32 tiles = sort_tiles(n);
+    if (!hist_ready) {
+        const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
+        hipLaunchKernelGGL(k_hist, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
+    }
+    hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist);
+    const u32* kin = keys_in; const u32* vin = vals_in;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) % 2) == 0;          // last pass lands in the caller's output
+        u32* kout = to_out ? keys_out : sc.tmp_keys;
+        u32* vout = to_out ? vals_out : sc.tmp_vals;
+        const int sh = start_bit + p * SORT_BITS;
+        const int w = (end_bit - sh) < SORT_BITS ? (end_bit - sh) : SORT_BITS;
+        const u32 mask = (1u << w) - 1u;
+        u32* st = sc.status + (size_t)p * tiles * SORT_RADIX;
+        if (vin == nullptr) hipLaunchKernelGGL(k_onesweep<true>,  dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p);
+        else                hipLaunchKernelGGL(k_onesweep<false>, dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p);
+        kin = kout; vin = vout;
+    }
+}
+
+} // namespace bvh

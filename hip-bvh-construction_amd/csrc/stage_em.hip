@@ -1,0 +1,211 @@
+// stage_em.hip — stage E (per-primitive AABB + scene extent) and stage M (30-bit extended Morton keys, with the
+// radix-sort digit histograms fused in) for gfx950.
+//
+// E replaces CalculateSceneExtents (reference src/CommonBlocksKernel.h:92-114, helpers :27-78, float atomics
+//   src/Common.h:291-307,400-408).  M replaces CalculateMortonCodes (src/CommonBlocksKernel.h:159-359,374-385).
+// Both are HBM-streaming kernels: E moves 64 B in / 24 B out per primitive, M 24 B in / 4 B out.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace bvh {
+
+// ------------------------------------------------------------------------------------------------------------------
+// E: one thread per primitive, grid-stride.  The 64-byte Triangle record holds 9 floats; they are fetched as
+// 2 x 16 B + 1 x 4 B so that no lane touches the 28 bytes of padding twice.  The block AABB is reduced with wave64
+// shuffles + one LDS hop, then 6 integer-punned float atomics per block fold it into the scene extent.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {   // atomicMinFloat, src/Common.h:291-298
+    if (__float_as_int(v) >= 0) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {   // atomicMaxFloat, src/Common.h:300-307
+    if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__device__ __forceinline__ Box wave_reduce_box(Box b) {
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) {
+        b.lx = fminf(b.lx, __shfl_xor(b.lx, m)); b.ly = fminf(b.ly, __shfl_xor(b.ly, m)); b.lz = fminf(b.lz, __shfl_xor(b.lz, m));
+        b.hx = fmaxf(b.hx, __shfl_xor(b.hx, m)); b.hy = fmaxf(b.hy, __shfl_xor(b.hy, m)); b.hz = fmaxf(b.hz, __shfl_xor(b.hz, m));
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(EM_BLOCK) void k_extents(const float4* __restrict__ tris, bvh_aabb* __restrict__ boxes,
+                                                      float* __restrict__ scene, u32 n) {
+    Box acc = box_empty();
+    const u32 stride = gridDim.x * EM_BLOCK;
+    for (u32 i = blockIdx.x * EM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 a = tris[(size_t)i * 4 + 0];
+        const float4 b = tris[(size_t)i * 4 + 1];
+        const float  c = reinterpret_cast<const float*>(tris + (size_t)i * 4 + 2)[0];
+        // v1 = (a.x,a.y,a.z)  v2 = (a.w,b.x,b.y)  v3 = (b.z,b.w,c)
+        Box bx;
+        bx.lx = fminf(fminf(a.x, a.w), b.z); bx.ly = fminf(fminf(a.y, b.x), b.w); bx.lz = fminf(fminf(a.z, b.y), c);
+        bx.hx = fmaxf(fmaxf(a.x, a.w), b.z); bx.hy = fmaxf(fmaxf(a.y, b.x), b.w); bx.hz = fmaxf(fmaxf(a.z, b.y), c);
+        box_store(boxes + i, bx);
+        acc = box_union(acc, bx);
+    }
+    acc = wave_reduce_box(acc);
+    __shared__ float red[EM_BLOCK / WAVE][6];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (lane == 0) { red[wave][0] = acc.lx; red[wave][1] = acc.ly; red[wave][2] = acc.lz; red[wave][3] = acc.hx; red[wave][4] = acc.hy; red[wave][5] = acc.hz; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < EM_BLOCK / WAVE; ++w) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomic_min_f32(scene + threadIdx.x, v); else atomic_max_f32(scene + threadIdx.x, v);
+    }
+}
+
+__global__ void k_reset_scene(float* scene) {   // Aabb::reset on d_sceneExtents (src/PLOC++Bvh.cpp:23-25)
+    if (threadIdx.x < 3) scene[threadIdx.x] = FMAX; else if (threadIdx.x < 6) scene[threadIdx.x] = -FMAX;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// M: the per-scene part of computeExtendedMortonCode (src/CommonBlocksKernel.h:162-275) depends only on the scene
+// extent, so one lane per block evaluates it once ("plan") and broadcasts it through LDS; every thread then only
+// quantises and interleaves.  Integer semantics follow the device code of the reference: float->int conversions
+// saturate (v_cvt_i32_f32), mixed int/u32 min/max promote to double (value-exact), u32 arithmetic wraps.
+// ------------------------------------------------------------------------------------------------------------------
+struct MortonPlan { int axis[3]; int bits[3]; int pre[2]; int pre_sum; int swap; };
+
+__device__ __forceinline__ int sat_f2i(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return -2147483647 - 1;
+    return (int)f;
+}
+__device__ __forceinline__ u32 sat_f2u(float f) {
+    if (f != f) return 0u;
+    if (f <= 0.0f) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (u32)f;
+}
+__device__ __forceinline__ int lg_ratio(float num, float den) { return sat_f2i(log2f(num / den)); }
+
+__device__ void make_plan(const float* __restrict__ scene, MortonPlan& m, float* lo, float* ext) {
+    lo[0] = scene[0]; lo[1] = scene[1]; lo[2] = scene[2];
+    const float ex = scene[3] - scene[0], ey = scene[4] - scene[1], ez = scene[5] - scene[2];
+    ext[0] = ex; ext[1] = ey; ext[2] = ez;
+    int px, py, pz;
+    // axis order by extent; the strict '<' chain of src/CommonBlocksKernel.h:167-250 decides ties
+    if (ex < ey) {
+        if (ex < ez) {
+            if (ey < ez) { m.axis[0] = 2; m.axis[1] = 1; m.axis[2] = 0; px = lg_ratio(ez, ey); py = lg_ratio(ey, ex); pz = lg_ratio(ez, ex); }
+            else         { m.axis[0] = 1; m.axis[1] = 2; m.axis[2] = 0; px = lg_ratio(ey, ez); py = lg_ratio(ez, ex); pz = lg_ratio(ey, ex); }
+        } else           { m.axis[0] = 1; m.axis[1] = 0; m.axis[2] = 2; px = lg_ratio(ey, ex); py = lg_ratio(ex, ez); pz = lg_ratio(ey, ez); }
+    } else {
+        if (ey < ez) {
+            if (ex < ez) { m.axis[0] = 2; m.axis[1] = 0; m.axis[2] = 1; px = lg_ratio(ez, ex); py = lg_ratio(ex, ey); pz = lg_ratio(ez, ey); }
+            else         { m.axis[0] = 0; m.axis[1] = 2; m.axis[2] = 1; px = lg_ratio(ex, ez); py = lg_ratio(ez, ey); pz = lg_ratio(ex, ey); }
+        } else           { m.axis[0] = 0; m.axis[1] = 1; m.axis[2] = 2; px = lg_ratio(ex, ey); py = lg_ratio(ey, ez); pz = lg_ratio(ex, ez); }
+    }
+    const u32 NB = 30u;
+    int swap = (int)((u32)pz - ((u32)px + (u32)py));                                   // :252
+    px = (int)fmin((double)px, (double)NB);                                            // :254
+    py = (int)(fmin((double)(int)((u32)py * 2u), (double)(NB - (u32)px)) / 2.0);       // :255
+    int sum = (int)((u32)px + (u32)py * 2u);                                           // :257
+    if (sum != (int)NB) sum = (int)((u32)sum + (u32)swap); else swap = 0;              // :259-262
+    const int bz = (ext[m.axis[2]] != 0.0f) ? (int)fmax(0.0, (double)((NB - (u32)sum) / 3u)) : 0;   // :264
+    int bx, by;
+    if (swap > 0) { bx = (int)fmax(0.0, (double)((NB - (u32)bz - (u32)sum) / 2u + (u32)py + (u32)px + 1u)); by = (int)(NB - (u32)bx - (u32)bz); }   // :266-270
+    else          { by = (int)fmax(0.0, (double)((NB - (u32)bz - (u32)sum) / 2u + (u32)py));                 bx = (int)(NB - (u32)by - (u32)bz); }   // :271-275
+    m.bits[0] = bx; m.bits[1] = by; m.bits[2] = bz; m.pre[0] = px; m.pre[1] = py; m.pre_sum = sum; m.swap = swap;
+}
+
+__device__ __forceinline__ u32 spread2(u32 v) {   // morton2D, :139-147
+    v &= 0x0000ffffu; v = (v ^ (v << 8)) & 0x00ff00ffu; v = (v ^ (v << 4)) & 0x0f0f0f0fu;
+    v = (v ^ (v << 2)) & 0x33333333u; v = (v ^ (v << 1)) & 0x55555555u; return v;
+}
+__device__ __forceinline__ u32 spread3(u32 x) {   // morton3D, :149-156
+    x = (x * 0x00010001u) & 0xFF0000FFu; x = (x * 0x00000101u) & 0x0F00F00Fu;
+    x = (x * 0x00000011u) & 0xC30C30C3u; x = (x * 0x00000005u) & 0x49249249u; return x;
+}
+__device__ __forceinline__ u32 shl(u32 v, u32 s) { return s >= 32u ? 0u : v << s; }
+__device__ __forceinline__ u32 shr(u32 v, u32 s) { return s >= 32u ? 0u : v >> s; }
+
+__device__ __forceinline__ u32 encode(const MortonPlan& m, float p0, float p1, float p2) {   // :277-358; p_k = position on axis[k]
+    int bx = m.bits[0], by = m.bits[1];
+    const int bz = m.bits[2], px = m.pre[0], py = m.pre[1];
+    u32 q0 = min(sat_f2u(fmaxf(p0 * (float)shl(1u, (u32)bx), 0.0f)), shl(1u, (u32)bx) - 1u);
+    u32 q1 = min(sat_f2u(fmaxf(p1 * (float)shl(1u, (u32)by), 0.0f)), shl(1u, (u32)by) - 1u);
+    u32 q2 = min(sat_f2u(fmaxf(p2 * (float)shl(1u, (u32)bz), 0.0f)), shl(1u, (u32)bz) - 1u);
+    u32 code = 0, d0 = 0, d1 = 0;
+    if (m.pre_sum > 0) {
+        bx -= px;
+        code = shr(q0 & shl(shl(1u, (u32)px) - 1u, (u32)bx), (u32)bx);
+        code = shl(code, (u32)(py * 2));
+        bx -= py; by -= py;
+        const u32 t0 = spread2(shr(q0 & shl(shl(1u, (u32)py) - 1u, (u32)bx), (u32)bx));
+        const u32 t1 = spread2(shr(q1 & shl(shl(1u, (u32)py) - 1u, (u32)by), (u32)by));
+        code |= t0 * 2 + t1;
+        if (m.swap > 0) { code <<= 1; bx -= 1; code |= shr(q0 & shl(1u, (u32)bx), (u32)bx); }
+        code = shl(code, (u32)(bx + by + bz));
+        q0 &= shl(1u, (u32)bx) - 1u;
+        q1 &= shl(1u, (u32)by) - 1u;
+        if (m.swap > 0) { d0 = (u32)(by - bx); q0 = shl(q0, d0); d1 = (u32)(by - bz); q2 = shl(q2, d1); }
+        else            { d0 = (u32)(bx - by); q1 = shl(q1, d0); d1 = (u32)(bx - bz); q2 = shl(q2, d1); }
+    }
+    if (bz == 0) code |= spread2(q0) * 2 + spread2(q1);
+    else {
+        const u32 X = spread3(q0), Y = spread3(q1), Z = spread3(q2);
+        code |= shr((m.swap > 0) ? (Y * 4 + X * 2 + Z) : (X * 4 + Y * 2 + Z), d0 + d1);
+    }
+    return code;
+}
+
+// HIST_BITS > 0: also accumulate the per-pass digit histograms of the LSD radix sort that follows (digits of HIST_BITS
+// bits starting at bit 0, `passes` of them) — LDS histogram per block, flushed with one global atomic per non-empty bin.
+template <int HIST_BITS>
+__global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
+                                                     u32* __restrict__ keys, u32* __restrict__ vals, u32 n,
+                                                     u32* __restrict__ hist, int passes) {
+    __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
+    constexpr int RADIX = HIST_BITS > 0 ? (1 << HIST_BITS) : 1;
+    __shared__ u32 s_hist[HIST_BITS > 0 ? 4 * RADIX : 1];
+    if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext);
+    if (HIST_BITS > 0) for (int i = threadIdx.x; i < passes * RADIX; i += EM_BLOCK) s_hist[i] = 0;
+    __syncthreads();
+    const MortonPlan m = s_plan;
+    const float lo[3] = { s_lo[0], s_lo[1], s_lo[2] }, ext[3] = { s_ext[0], s_ext[1], s_ext[2] };
+    const u32 stride = gridDim.x * EM_BLOCK;
+    for (u32 i = blockIdx.x * EM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const Box b = box_load(boxes + i);
+        // centre = (max + min) * 0.5f (src/Common.h:347); p = (centre - scene.min) / extent with IEEE divides (:381)
+        const float p[3] = { ((b.hx + b.lx) * 0.5f - lo[0]) / ext[0], ((b.hy + b.ly) * 0.5f - lo[1]) / ext[1], ((b.hz + b.lz) * 0.5f - lo[2]) / ext[2] };
+        const u32 code = encode(m, p[m.axis[0]], p[m.axis[1]], p[m.axis[2]]);
+        keys[i] = code;
+        if (vals) vals[i] = i;                                   // :384
+        if (HIST_BITS > 0) {
+            for (int ps = 0; ps < passes; ++ps) atomicAdd(&s_hist[ps * RADIX + ((code >> (ps * HIST_BITS)) & (RADIX - 1))], 1u);
+        }
+    }
+    if (HIST_BITS > 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < passes * RADIX; i += EM_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&hist[i], c); }
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+static inline int em_grid(u32 n) {
+    const u32 blocks = (n + EM_BLOCK - 1) / EM_BLOCK;
+    return (int)(blocks < 2048u ? (blocks ? blocks : 1u) : 2048u);   // 256 CUs x 8 blocks, grid-stride beyond
+}
+
+void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene) {
+    hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
+    hipLaunchKernelGGL(k_extents, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+}
+
+void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
+                   u32* d_hist, int hist_bits, int passes) {
+    const dim3 g(em_grid(n)), b(EM_BLOCK);
+    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
+    else if (d_hist && hist_bits == 10) hipLaunchKernelGGL(k_morton<10>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
+    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0);
+}
+
+} // namespace bvh

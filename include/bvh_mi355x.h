@@ -1,0 +1,136 @@
+/* bvh_mi355x.h — C ABI of the MI355X-native BVH build path (extent -> Morton -> radix sort -> hierarchy emit).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repo root).  The C++ classes in
+ * include/bvh/builders.hpp (same names/signatures as the reference's builders) are thin wrappers over these.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative value on failure (-(int)hipError_t, or BVH_E_*);
+ *     nothing throws, nothing prints (the reference's CHECK_ORO logs and continues, src/Error.cpp:9-17).
+ *   - a bvh_ctx is bound to one device and one HIP stream; calls on one ctx are serialised on its stream;
+ *     different ctxs are independent (one ctx per GPU / per host thread for the batched builder).
+ *   - "d_" pointers are device pointers on the ctx's device.  Layouts are those of include/bvh/types.h
+ *     (= src/Common.h:310-441,574-578 of the reference).
+ *   - there is NO CPU fallback: if the HIP runtime or a gfx950 device is missing, bvh_ctx_create fails.
+ */
+#ifndef BVH_MI355X_H
+#define BVH_MI355X_H
+
+#include <stdint.h>
+#include "bvh/types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVH_E_INVALID_ARG   (-10001)
+#define BVH_E_TOO_LARGE     (-10002)   /* n >= 2^30 (status words of the one-sweep sort carry 30-bit counts) */
+#define BVH_E_NOT_BUILT     (-10003)
+#define BVH_E_INTERNAL      (-10004)   /* a device-side consistency check failed (e.g. HPLOC node count != n-1) */
+
+typedef struct bvh_ctx bvh_ctx;
+
+/* Replaces Context::Context() (src/Context.cpp:7-15: device 0 hard coded) — here any device, own stream. */
+int  bvh_ctx_create(int device, bvh_ctx** out);
+/* Same, but work is enqueued on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int  bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out);
+void bvh_ctx_destroy(bvh_ctx* ctx);
+/* Pre-size the ctx's device arena for builds of up to n primitives (otherwise grown lazily, outside timed regions). */
+int  bvh_ctx_reserve(bvh_ctx* ctx, uint32_t n);
+int  bvh_ctx_device(const bvh_ctx* ctx);
+void* bvh_ctx_stream(const bvh_ctx* ctx);
+
+/* Builder selection = the reference's compile-time switch in src/main.cpp:18-22. */
+typedef enum {
+    BVH_LBVH_TWOPASS    = 0,   /* TwoPassLbvh::build    src/TwoPassLbvh.cpp:17-197    */
+    BVH_LBVH_SINGLEPASS = 1,   /* SinglePassLbvh::build src/SinglePassLbvh.cpp:17-188 */
+    BVH_PLOCPP          = 2,   /* PLOCNew::build        src/PLOC++Bvh.cpp:16-196      */
+    BVH_HPLOC           = 3    /* HPLOC::build          src/Hploc.cpp:16-165          */
+} bvh_algo;
+
+/* Per-stage times, same tokens as the reference's Timer (src/Common.h:418-427, src/Timer.h:31-73).
+ * ms_total = extents + morton + sort + build  (the reference's "Total Time", src/TwoPassLbvh.cpp:308-309).
+ * Filled only when profiling is enabled on the ctx (bvh_ctx_set_profiling); otherwise all zero. */
+typedef struct {
+    float    ms_extents, ms_morton, ms_sort, ms_build, ms_collapse, ms_total;
+    uint32_t ploc_iterations;          /* PLOC++: NN/merge rounds executed on device */
+    uint32_t reserved;
+    uint64_t bytes_algorithmic;        /* DESIGN.md "algorithmic bytes" for this build (n x per-prim figure) */
+} bvh_timings;
+int  bvh_ctx_set_profiling(bvh_ctx* ctx, int enabled);
+
+/* Result of a build.  All pointers are device pointers owned by the ctx; they stay valid until the next
+ * bvh_build on the same ctx or bvh_ctx_destroy.  Mirrors the public members of the reference builders
+ * (src/TwoPassLbvh.h:19-31, src/PLOC++Bvh.h:19-32):
+ *   LBVH layouts : d_nodes = Bvh2Node[2n-1], internal [0,n-1), leaf i at n-1+i {left=primIdx,right=INVALID}; d_leaves = NULL
+ *   PLOC layouts : d_nodes = Bvh2Node[n-1], d_leaves = PrimRef[n] in Morton order, child >= n-1 -> leaves[child-(n-1)], root 0 */
+typedef struct {
+    void*    d_nodes;
+    void*    d_leaves;
+    void*    d_prim_aabbs;        /* Aabb[n] by original primitive index (d_triangleAabb) */
+    void*    d_scene_extent;      /* Aabb[1] (d_sceneExtents) */
+    void*    d_sorted_keys;       /* u32[n] (d_sortedMortonCodeKeys)   */
+    void*    d_sorted_vals;       /* u32[n] (d_sortedMortonCodeValues) */
+    uint32_t root;                /* BVH2 root index (m_rootNodeIdx; single-pass LBVH: data dependent) */
+    uint32_t n_internal;          /* n - 1 (m_nInternalNodes) */
+    uint32_t n_leaves;            /* n */
+    uint32_t layout;              /* 0 = LBVH layout, 1 = PLOC layout */
+} bvh_result;
+
+/* X::build(Context&, std::vector<Triangle>&).  tris: Triangle[n], 64-byte stride, host (tris_on_device = 0: copied H2D
+ * into the ctx arena, untimed, as src/TwoPassLbvh.cpp:19-20 does) or device (tris_on_device = 1: used in place). n >= 2. */
+int  bvh_build(bvh_ctx* ctx, bvh_algo algo, const void* tris, uint32_t n, int tris_on_device,
+               bvh_result* out, bvh_timings* timings /* may be NULL */);
+
+/* ---- stage-level entry points (one per reference kernel / library call on the path) -------------------------- */
+
+/* CalculateSceneExtents (src/CommonBlocksKernel.h:92-114): Triangle[n] -> Aabb[n] + scene Aabb.
+ * d_scene_extent is reset to {+FltMax,-FltMax} first (src/PLOC++Bvh.cpp:23-25). */
+int  bvh_stage_extents(bvh_ctx* ctx, const void* d_tris, uint32_t n, void* d_prim_aabbs, void* d_scene_extent);
+/* CalculateMortonCodes (src/CommonBlocksKernel.h:374-385): 30-bit extended Morton keys, values = 0..n-1. d_vals may be NULL. */
+int  bvh_stage_morton(bvh_ctx* ctx, const void* d_prim_aabbs, uint32_t n, const void* d_scene_extent,
+                      uint32_t* d_keys, uint32_t* d_vals);
+/* Oro::RadixSort::sort(KeyValueSoA src, KeyValueSoA dst, n, startBit, endBit, stream)
+ * (call sites src/TwoPassLbvh.cpp:71-89 ...): stable ascending LSD radix sort on key bits [start_bit, end_bit).
+ * d_vals_in == NULL sorts (key, index) pairs.  src is not modified. */
+int  bvh_sort_pairs(bvh_ctx* ctx, const uint32_t* d_keys_in, const uint32_t* d_vals_in, uint32_t n,
+                    uint32_t* d_keys_out, uint32_t* d_vals_out, int start_bit, int end_bit);
+/* InitBvhNodes + BvhBuildAndFit (src/SinglePassLbvhKernel.h:27-126) -> Bvh2Node[2n-1], *root_out = root index */
+int  bvh_emit_lbvh_single(bvh_ctx* ctx, const void* d_prim_aabbs, const uint32_t* d_sorted_keys,
+                          const uint32_t* d_sorted_vals, uint32_t n, void* d_nodes, uint32_t* root_out);
+/* InitBvhNodesPrimRef + BvhBuild + FitBvhNodes (src/TwoPassLbvhKernel.h:164-235) -> Bvh2Node[2n-1], root 0 */
+int  bvh_emit_lbvh_two(bvh_ctx* ctx, const void* d_prim_aabbs, const uint32_t* d_sorted_keys,
+                       const uint32_t* d_sorted_vals, uint32_t n, void* d_nodes);
+/* SetupClusters + Ploc/SinglePassPloc + host loop (src/Ploc++Kernel.h:39-362, src/PLOC++Bvh.cpp:132-152) */
+int  bvh_emit_ploc(bvh_ctx* ctx, const void* d_prim_aabbs, const uint32_t* d_sorted_vals, uint32_t n,
+                   void* d_nodes, void* d_leaves, uint32_t* iterations_out);
+/* SetupClusters + HPloc (src/HplocKernel.h:39-315) */
+int  bvh_emit_hploc(bvh_ctx* ctx, const void* d_prim_aabbs, const uint32_t* d_sorted_keys,
+                    const uint32_t* d_sorted_vals, uint32_t n, void* d_nodes, void* d_leaves);
+
+/* ---- consumers' helpers --------------------------------------------------------------------------------------- */
+/* PLOC layout -> LBVH layout (Bvh2Node[2n-1]) so that the reference's traversal kernels (src/TraversalKernel.h) can
+ * consume PLOC/HPLOC trees; the adapter the reference never wrote. */
+int  bvh_to_lbvh_layout(bvh_ctx* ctx, const bvh_result* in, void* d_nodes_2n_minus_1);
+/* BVH2 SAH cost with the formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349), device reduction, f64. */
+int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
+/* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL */
+int  bvh_download(bvh_ctx* ctx, const bvh_result* in, void* h_nodes, void* h_leaves, uint32_t* h_sorted_keys,
+                  uint32_t* h_sorted_vals, void* h_scene_extent);
+
+/* wait for everything enqueued on the ctx's stream (bvh_build is asynchronous unless it has to read something back:
+ * profiling on, single-pass root index, PLOC++ iteration batches) */
+int  bvh_ctx_synchronize(bvh_ctx* ctx);
+
+/* plain device-memory helpers so that hosts without a HIP binding (ctypes, cgo, JNI ...) can stage buffers */
+int  bvh_dev_alloc(bvh_ctx* ctx, uint64_t bytes, void** out);
+int  bvh_dev_free(bvh_ctx* ctx, void* p);
+int  bvh_dev_upload(bvh_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+int  bvh_dev_download(bvh_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+
+const char* bvh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

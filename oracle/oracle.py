@@ -1,0 +1,239 @@
+"""ctypes binding of the CPU oracle (oracle/libbvh_oracle.so) and of the reference builds under oracle/_ref/.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package.  See oracle/bvh_oracle.cpp for what each function restates (reference file:line).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "libbvh_oracle.so")
+REF_UTILITY = os.path.join(_HERE, "_ref", "libref_utility.so")
+REF_DRIVER = os.path.join(_HERE, "_ref", "libref_driver.so")
+
+AABB = np.dtype([("min", "<f4", 3), ("max", "<f4", 3)])
+TRIANGLE = np.dtype([("v1", "<f4", 3), ("v2", "<f4", 3), ("v3", "<f4", 3), ("pad", "<f4", 7)])
+BVH2_NODE = np.dtype([("left", "<u4"), ("right", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
+PRIMREF = np.dtype([("prim", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
+SAH_NODE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("first", "<u4"), ("count", "<u4")])
+BVH4_NODE = np.dtype([("aabb", AABB, 4), ("child", "<u4", 4), ("parent", "<u4"), ("count", "<u4"), ("pad", "<u4", 2)])
+PRIM_NODE = np.dtype([("prim", "<u4"), ("parent", "<u4")])
+assert BVH4_NODE.itemsize == 128 and SAH_NODE.itemsize == 32
+STATS = np.dtype([("iterations", "<u8"), ("cluster_loads", "<u8"), ("cluster_stores", "<u8"), ("merge_calls", "<u8"), ("nn_rounds", "<u8")])
+
+
+def build(ref: bool = True) -> None:
+    """make -C oracle (own restatement always; reference builds only where /root/reference exists)."""
+    targets = ["libbvh_oracle.so"] + (["ref"] if ref else [])
+    r = subprocess.run(["make", "-C", _HERE] + targets, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build(ref=False)
+        L = C.CDLL(LIB)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        L.orc_prim_bounds.argtypes = [vp, u32, vp, vp]
+        L.orc_primrefs.argtypes = [vp, u32, vp]
+        L.orc_morton_plan.argtypes = [vp, vp]
+        L.orc_morton_codes.argtypes = [vp, u32, u32, u32, vp, vp, vp]
+        L.orc_sort_pairs.argtypes = [vp, vp, u32, vp, vp]
+        L.orc_lbvh_single.argtypes = [vp, u32, vp, vp, vp]; L.orc_lbvh_single.restype = u32
+        L.orc_lbvh_two.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.orc_ploc.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.orc_hploc.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.orc_sah_bvh2.argtypes = [vp, vp, u32, u32, C.c_int, C.POINTER(C.c_float)]; L.orc_sah_bvh2.restype = C.c_double
+        L.orc_validate_bvh2.argtypes = [vp, vp, u32, u32, C.c_int]; L.orc_validate_bvh2.restype = C.c_int
+        L.orc_topology_hash.argtypes = [vp, vp, u32, u32, C.c_int]; L.orc_topology_hash.restype = u64
+        L.orc_fnv1a.argtypes = [vp, u64]; L.orc_fnv1a.restype = u64
+        L.orc_ploc_to_lbvh_layout.argtypes = [vp, vp, u32, vp]
+        L.orc_binned_sah_build.argtypes = [vp, u32, vp]; L.orc_binned_sah_build.restype = u32
+        L.orc_sah_binned.argtypes = [vp, u32, u32, C.POINTER(C.c_float)]; L.orc_sah_binned.restype = C.c_double
+        L.orc_collapse4.argtypes = [vp, vp, u32, u32, C.c_int, vp, vp]; L.orc_collapse4.restype = u32
+        L.orc_sah_bvh4.argtypes = [vp, vp, vp, u32, u32, C.POINTER(C.c_float)]; L.orc_sah_bvh4.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else np.ascontiguousarray(a).ctypes.data
+
+
+# ---- stages -------------------------------------------------------------------------------------------------------
+def prim_bounds(tris: np.ndarray):
+    n = tris.shape[0]
+    boxes = np.empty(n, dtype=AABB); scene = np.empty(1, dtype=AABB)
+    lib().orc_prim_bounds(tris.ctypes.data, n, boxes.ctypes.data, scene.ctypes.data)
+    return boxes, scene
+
+
+def primrefs(tris: np.ndarray) -> np.ndarray:
+    refs = np.empty(tris.shape[0], dtype=PRIMREF)
+    lib().orc_primrefs(tris.ctypes.data, tris.shape[0], refs.ctypes.data)
+    return refs
+
+
+def morton_plan(scene: np.ndarray) -> dict:
+    p = np.zeros(10, dtype=np.int32)
+    lib().orc_morton_plan(scene.ctypes.data, p.ctypes.data)
+    return {"axis": p[0:3].tolist(), "bits": p[3:6].tolist(), "pre": p[6:8].tolist(), "pre_sum": int(p[8]), "swap": int(p[9])}
+
+
+def morton_codes(boxes: np.ndarray, scene: np.ndarray):
+    n = boxes.shape[0]
+    keys = np.empty(n, dtype=np.uint32); vals = np.empty(n, dtype=np.uint32)
+    lib().orc_morton_codes(boxes.ctypes.data, boxes.dtype.itemsize, 0, n, scene.ctypes.data, keys.ctypes.data, vals.ctypes.data)
+    return keys, vals
+
+
+def sort_pairs(keys: np.ndarray, vals: np.ndarray | None = None):
+    n = keys.shape[0]
+    sk = np.empty(n, dtype=np.uint32); sv = np.empty(n, dtype=np.uint32)
+    lib().orc_sort_pairs(keys.ctypes.data, _p(vals), n, sk.ctypes.data, sv.ctypes.data)
+    return sk, sv
+
+
+def front_end(tris: np.ndarray):
+    """E + M + S -> dict(boxes, scene, keys, skeys, svals)"""
+    boxes, scene = prim_bounds(tris)
+    keys, vals = morton_codes(boxes, scene)
+    sk, sv = sort_pairs(keys, vals)
+    return {"boxes": boxes, "scene": scene, "keys": keys, "skeys": sk, "svals": sv}
+
+
+# ---- emitters -----------------------------------------------------------------------------------------------------
+def lbvh_single(tris, skeys, svals):
+    n = tris.shape[0]
+    nodes = np.zeros(2 * n - 1, dtype=BVH2_NODE)
+    root = lib().orc_lbvh_single(tris.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data)
+    return nodes, int(root)
+
+
+def lbvh_two(tris, skeys, svals):
+    n = tris.shape[0]
+    refs = primrefs(tris)
+    nodes = np.zeros(2 * n - 1, dtype=BVH2_NODE)
+    parents = np.empty(2 * n - 1, dtype=np.uint32)
+    lib().orc_lbvh_two(refs.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, parents.ctypes.data)
+    return nodes, parents
+
+
+def ploc(boxes, svals):
+    n = boxes.shape[0]
+    nodes = np.zeros(n - 1, dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); st = np.zeros(1, dtype=STATS)
+    lib().orc_ploc(boxes.ctypes.data, n, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, st.ctypes.data)
+    return nodes, leaves, {k: int(st[k][0]) for k in STATS.names}
+
+
+def hploc(boxes, skeys, svals):
+    n = boxes.shape[0]
+    nodes = np.zeros(n - 1, dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); st = np.zeros(1, dtype=STATS)
+    lib().orc_hploc(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, st.ctypes.data)
+    return nodes, leaves, {k: int(st[k][0]) for k in STATS.names}
+
+
+def build_tree(algo: int, tris: np.ndarray) -> dict:
+    """Whole pipeline on the CPU.  algo: 0 two-pass, 1 single-pass, 2 PLOC++, 3 HPLOC."""
+    fe = front_end(tris)
+    out = dict(fe)
+    if algo == 1:
+        nodes, root = lbvh_single(tris, fe["skeys"], fe["svals"]); out.update(nodes=nodes, leaves=None, root=root, layout=0)
+    elif algo == 0:
+        nodes, _ = lbvh_two(tris, fe["skeys"], fe["svals"]); out.update(nodes=nodes, leaves=None, root=0, layout=0)
+    elif algo == 2:
+        nodes, leaves, st = ploc(fe["boxes"], fe["svals"]); out.update(nodes=nodes, leaves=leaves, root=0, layout=1, stats=st)
+    elif algo == 3:
+        nodes, leaves, st = hploc(fe["boxes"], fe["skeys"], fe["svals"]); out.update(nodes=nodes, leaves=leaves, root=0, layout=1, stats=st)
+    else:
+        raise ValueError(algo)
+    return out
+
+
+# ---- checks -------------------------------------------------------------------------------------------------------
+def sah_bvh2(nodes, leaves, root, n, layout):
+    f = C.c_float()
+    c = lib().orc_sah_bvh2(nodes.ctypes.data, _p(leaves), root, n, layout, C.byref(f))
+    return float(c), float(f.value)
+
+
+def validate_bvh2(nodes, leaves, root, n, layout) -> int:
+    return int(lib().orc_validate_bvh2(nodes.ctypes.data, _p(leaves), root, n, layout))
+
+
+def topology_hash(nodes, leaves, root, n, layout) -> int:
+    return int(lib().orc_topology_hash(nodes.ctypes.data, _p(leaves), root, n, layout))
+
+
+def fnv1a(a: np.ndarray) -> int:
+    a = np.ascontiguousarray(a)
+    return int(lib().orc_fnv1a(a.ctypes.data, a.nbytes))
+
+
+def ploc_to_lbvh_layout(nodes, leaves):
+    n = leaves.shape[0]
+    out = np.zeros(2 * n - 1, dtype=BVH2_NODE)
+    lib().orc_ploc_to_lbvh_layout(nodes.ctypes.data, leaves.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def binned_sah_build(tris):
+    n = tris.shape[0]
+    nodes = np.zeros(3 * n - 1, dtype=SAH_NODE)
+    total = lib().orc_binned_sah_build(tris.ctypes.data, n, nodes.ctypes.data)
+    return nodes, int(total)
+
+
+def sah_binned(nodes, total, n):
+    f = C.c_float()
+    c = lib().orc_sah_binned(nodes.ctypes.data, total, n, C.byref(f))
+    return float(c), float(f.value)
+
+
+def collapse4(nodes, leaves, root, n, layout):
+    w = np.zeros(n, dtype=BVH4_NODE); pn = np.zeros(n, dtype=PRIM_NODE)
+    total = lib().orc_collapse4(nodes.ctypes.data, _p(leaves), root, n, layout, w.ctypes.data, pn.ctypes.data)
+    return w, pn, int(total)
+
+
+def sah_bvh4(w, pn, prim_boxes, total, n):
+    f = C.c_float()
+    c = lib().orc_sah_bvh4(w.ctypes.data, pn.ctypes.data, prim_boxes.ctypes.data, total, n, C.byref(f))
+    return float(c), float(f.value)
+
+
+# ---- the reference's own Utility.cpp (oracle/_ref/libref_utility.so), when built ------------------------------------
+_ref = None
+
+
+def ref_utility():
+    """The reference's unmodified src/Utility.cpp behind extern "C" shims, or None if oracle/_ref was not built."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(REF_UTILITY):
+            return None
+        L = C.CDLL(REF_UTILITY)
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.ref_calculateLbvhCost.argtypes = [vp, u32, u32, u32]; L.ref_calculateLbvhCost.restype = C.c_float
+        for name in ("ref_checkLbvhRootAabb", "ref_checkLBvhCorrectness"):
+            getattr(L, name).argtypes = [vp, u32, u32, u32]; getattr(L, name).restype = C.c_int
+        L.ref_checkPlocBvh2Correctness.argtypes = [vp, vp, u32, u32, u32]; L.ref_checkPlocBvh2Correctness.restype = C.c_int
+        L.ref_checkLBvh4Correctness.argtypes = [vp, vp, u32, u32]; L.ref_checkLBvh4Correctness.restype = C.c_int
+        L.ref_calculatebvh4Cost.argtypes = [vp, vp, vp, u32, u32, u32]; L.ref_calculatebvh4Cost.restype = C.c_float
+        L.ref_calculateBinnedSahBvhCost.argtypes = [vp, u32, u32]; L.ref_calculateBinnedSahBvhCost.restype = C.c_float
+        L.ref_loadScene.argtypes = [C.c_char_p, C.c_char_p, vp, u32]; L.ref_loadScene.restype = u32
+        L.ref_primRefs.argtypes = [vp, u32, vp]; L.ref_primRefs.restype = u32
+        L.ref_sizeof.argtypes = [C.c_int]; L.ref_sizeof.restype = u32
+        _ref = L
+    return _ref
