@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — BVH build throughput on MI355X (metric of BASELINE.json: build Mtris/s over extents+Morton+sort+emit).
+
+One step = one complete build (stage E, M, S, B) of a synthetic mesh whose triangles are already resident in HBM.
+N = 1: the configuration the metric is quoted on — 10 M-triangle uniform-random mesh, HPLOC (BASELINE.json configs[2]).
+N > 1: one process per GPU (launched by torch.distributed.run), every rank builds its own mesh of the same size (different
+seed) — the path shards at scene granularity, no data-path collective; the only exchange is an all-gather of the 24-byte
+root AABBs (RCCL) per step.  scaling = weak.  value = triangles built by all ranks / time of K steps (max over ranks).
+
+Also reported on the same JSON line:
+  roofline     — dominant kernel's algorithmic bytes / its HIP-event time (events recorded on the launch stream inside the
+                 timed region) against the 8 TB/s HBM peak;
+  cpu_baseline — the reference's CPU binned-SAH builder (oracle port, 1 thread) timed on a bounded sample of the same mesh.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+# algorithmic bytes per primitive of each kernel (restated in DESIGN.md §5)
+KERNEL_BYTES_PER_PRIM = {
+    "k_extents": 88.0,            # R Triangle 64 + W Aabb 24
+    "k_morton": 32.0,             # R Aabb 24 + W key 4 + W val 4   (this build: 28, value is implicit)
+    "k_onesweep": 17.0,           # per pass: R 8 + W 8 (+ hist R 4 amortised over 4 passes)
+    "k_setup_clusters": 64.0,     # R val 4 + gather Aabb 24 + W PrimRef 28 + W nodeIdx 4 + W parentIdx 4
+    "k_hploc": 134.0,             # keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32
+    "k_lbvh_single": 224.0,
+    "k_karras": 100.0, "k_refit": 88.0,
+    "k_ploc_iter": 190.0,         # summed over all iterations
+}
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tris", type=int, default=10_000_000)
+    ap.add_argument("--algo", default="hploc", choices=["hploc", "ploc", "lbvh_single", "lbvh_two"])
+    ap.add_argument("--mesh", default="uniform", choices=["uniform", "bunny", "sponza"])
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="triangles of the mesh the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import bvh_pkg
+    pkg = bvh_pkg.load()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+
+    algo = {"hploc": pkg.ALGO_HPLOC, "ploc": pkg.ALGO_PLOCPP, "lbvh_single": pkg.ALGO_SINGLEPASS, "lbvh_two": pkg.ALGO_TWOPASS}[args.algo]
+    n = args.tris
+    seed = 1 + rank
+    t0 = time.time()
+    if args.mesh == "uniform":
+        tris = pkg.meshgen.uniform(n, seed, offset=(float(rank), 0.0, 0.0))
+    elif args.mesh == "bunny":
+        tris = pkg.meshgen.bunny_like(n, seed + 1)
+    else:
+        tris = pkg.meshgen.sponza_like(n, seed + 2)
+    gen_s = time.time() - t0
+
+    # work is enqueued on torch's current stream so that the RCCL all-gather is ordered after the build
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = pkg.Context(local, stream if stream else None)
+    d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()      # input resident in HBM before the timed region
+    ctx.reserve(n)
+    builder = pkg.BUILDERS[algo]()
+    root_box = torch.zeros(6, dtype=torch.float32, device="cuda")
+    gathered = torch.zeros(6 * world, dtype=torch.float32, device="cuda") if world > 1 else None
+    lib = pkg.lib()
+    import ctypes as C
+
+    def step():
+        builder.build(ctx, d_tris, on_device=True, n=n)
+        if world > 1:
+            # root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
+            src = builder.result.d_nodes + 32 * builder.result.root + 8
+            rc = lib.bvh_dev_copy(ctx.handle, root_box.data_ptr(), src, 24)
+            assert rc == 0
+            dist.all_gather_into_tensor(gathered, root_box)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_profiling(0)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.set_profiling(0 if args.no_kernel_events else 2)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ktimes = {} if args.no_kernel_events else ctx.kernel_times()
+    ctx.set_profiling(1)
+    builder.build(ctx, d_tris, on_device=True, n=n)          # one extra build with stage events (reference Timer tokens)
+    stage = dict(builder.m_timer)
+    sah = builder.sah_cost()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = (n * world) / (elapsed / args.steps) / 1e6
+    # ---- roofline of the dominant kernel (largest summed event time)
+    roof = None
+    if ktimes:
+        dom = max(ktimes.items(), key=lambda kv: kv[1][0])
+        name, (ms_sum, launches) = dom
+        per_build_ms = ms_sum / args.steps                      # all launches of that kernel in one build
+        launches_per_build = launches / args.steps
+        alg_bytes = KERNEL_BYTES_PER_PRIM.get(name, 0.0) * n * (launches_per_build if name == "k_onesweep" else 1.0)
+        achieved = alg_bytes / (per_build_ms * 1e-3) / 1e9 if per_build_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"{name}@{n}")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(ms_sum / launches, 4), "launches_per_step": launches_per_build,
+                "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_build, 1.0) if name == "k_onesweep" else alg_bytes}
+    # ---- CPU baseline: reference's binned-SAH builder (oracle port), single thread, bounded sample of the same mesh
+    cpu = None
+    if args.cpu_sample > 0:
+        import oracle as orc
+        m = min(args.cpu_sample, n)
+        sample = np.ascontiguousarray(tris[:m])
+        t0 = time.perf_counter()
+        nodes, total = orc.binned_sah_build(sample)
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(m / dt / 1e6, 4), "unit": "Mtris/s", "cores": 1, "kind": "port",
+               "sample": f"first {m} triangles of the benchmark mesh, oracle port of SahBvh::build (src/BinnedSahBvh.cpp:13-203), {dt:.1f} s",
+               "sah": round(orc.sah_binned(nodes, total, m)[0], 4)}
+    out = {
+        "metric": "bvh_build_throughput", "value": round(value, 2), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.mesh}_{n}_tris_{args.algo}", "builder": pkg.ALGO_NAMES[algo], "tris_per_gpu": n, "mesh": args.mesh,
+                   "seed": "1+rank", "parallelism": f"scene-shard x{world}" + (" + allgather(root aabb)" if world > 1 else "")},
+        "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+        "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items()},
+        "sah_bvh2": round(sah, 4),
+        "pipeline_roofline": {"algorithmic_bytes": int(builder.timings.bytes_algorithmic),
+                              "achieved_GBs": round(builder.timings.bytes_algorithmic / (ms_per_step * 1e-3) / 1e9, 1),
+                              "frac": round(builder.timings.bytes_algorithmic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "roofline": roof, "cpu_baseline": cpu, "mesh_gen_s": round(gen_s, 2),
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

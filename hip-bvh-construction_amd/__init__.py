@@ -35,9 +35,9 @@ ALGO_NAMES = {0: "TwoPassLbvh", 1: "SinglePassLbvh", 2: "PLOCNew", 3: "HPLOC"}
 # every symbol include/bvh_mi355x.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
-    "bvh_ctx_set_profiling", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
+    "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_sah_cost",
-    "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_version",
+    "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_version",
 ]
 
 
@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         "bvh_download": ([vp, C.POINTER(Result), vp, vp, vp, vp, vp], i32),
         "bvh_dev_alloc": ([vp, u64, C.POINTER(vp)], i32), "bvh_dev_free": ([vp, vp], i32),
         "bvh_dev_upload": ([vp, vp, vp, u64], i32), "bvh_dev_download": ([vp, vp, vp, u64], i32),
+        "bvh_dev_copy": ([vp, vp, vp, u64], i32),
+        "bvh_ctx_kernel_times": ([vp, C.c_char_p, u32, C.POINTER(C.c_float), C.POINTER(u32), u32], i32),
         "bvh_version": ([], C.c_char_p),
     }
     for name, (args, res) in sig.items():
@@ -169,8 +171,18 @@ class Context:
         self.handle = h
         self.device = device
 
-    def set_profiling(self, on: bool) -> None:
-        _check(lib().bvh_ctx_set_profiling(self.handle, int(on)), "bvh_ctx_set_profiling")
+    def set_profiling(self, level) -> None:
+        """0 off, 1 stage events (reference Timer tokens), 2 + per-kernel events"""
+        _check(lib().bvh_ctx_set_profiling(self.handle, int(level)), "bvh_ctx_set_profiling")
+
+    def kernel_times(self) -> dict:
+        """{kernel name: (summed ms, launches)} since set_profiling(2)"""
+        names = C.create_string_buffer(4096); ms = (C.c_float * 64)(); cnt = (C.c_uint32 * 64)()
+        k = lib().bvh_ctx_kernel_times(self.handle, names, 4096, ms, cnt, 64)
+        if k < 0:
+            _check(k, "bvh_ctx_kernel_times")
+        nm = names.value.decode().split("\n")
+        return {nm[i]: (float(ms[i]), int(cnt[i])) for i in range(k)}
 
     def reserve(self, n: int) -> None:
         _check(lib().bvh_ctx_reserve(self.handle, n), "bvh_ctx_reserve")

@@ -8,13 +8,33 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#include <vector>
+#include <string>
+#include <map>
+
 using namespace bvh;
+
+namespace bvh { thread_local KernelRecorder* g_recorder = nullptr; }
+
+struct EventRecorder : KernelRecorder {
+    struct Rec { const char* name; hipEvent_t a, b; };
+    std::vector<Rec> recs; size_t used = 0;
+    void begin(hipStream_t s, const char* name) override {
+        if (used == recs.size()) { Rec r{name, nullptr, nullptr}; if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; recs.push_back(r); }
+        recs[used].name = name; (void)hipEventRecord(recs[used].a, s);
+    }
+    void end(hipStream_t s) override { if (used < recs.size()) { (void)hipEventRecord(recs[used].b, s); ++used; } }
+    void reset() { used = 0; }
+    ~EventRecorder() override { for (auto& r : recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); } }
+};
 
 struct bvh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool profiling = false;
+    bool profiling = false;           // stage-level events (the reference's Timer tokens)
+    bool kernel_profiling = false;    // + one event pair per kernel launch
+    EventRecorder recorder;
     uint32_t cap = 0;                 // primitives the arena is sized for
     char* arena = nullptr;
     size_t arena_bytes = 0;
@@ -168,7 +188,31 @@ void bvh_ctx_destroy(bvh_ctx* c) {
 int bvh_ctx_reserve(bvh_ctx* c, uint32_t n) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return ensure_capacity(c, n); }
 int bvh_ctx_device(const bvh_ctx* c) { return c ? c->device : -1; }
 void* bvh_ctx_stream(const bvh_ctx* c) { return c ? (void*)c->stream : nullptr; }
-int bvh_ctx_set_profiling(bvh_ctx* c, int enabled) { if (!c) return BVH_E_INVALID_ARG; c->profiling = enabled != 0; return 0; }
+int bvh_ctx_set_profiling(bvh_ctx* c, int level) {
+    if (!c) return BVH_E_INVALID_ARG;
+    c->profiling = level != 0; c->kernel_profiling = level >= 2; c->recorder.reset();
+    return 0;
+}
+
+// Sum of the per-kernel event times recorded since the last bvh_ctx_set_profiling(ctx, 2).  Synchronises the stream.
+// names_out: buffer for '\n'-separated kernel names; ms_out/count_out: per distinct kernel (order of first launch).
+int bvh_ctx_kernel_times(bvh_ctx* c, char* names_out, uint32_t names_cap, float* ms_out, uint32_t* count_out, uint32_t max_kernels) {
+    if (!c) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<std::string> order; std::map<std::string, std::pair<double, uint32_t>> acc;
+    for (size_t i = 0; i < c->recorder.used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->recorder.recs[i].a, c->recorder.recs[i].b));
+        auto it = acc.find(c->recorder.recs[i].name);
+        if (it == acc.end()) { order.push_back(c->recorder.recs[i].name); acc[c->recorder.recs[i].name] = {ms, 1u}; }
+        else { it->second.first += ms; it->second.second += 1; }
+    }
+    std::string names; uint32_t k = 0;
+    for (auto& nme : order) { if (k >= max_kernels) break; if (ms_out) ms_out[k] = (float)acc[nme].first; if (count_out) count_out[k] = acc[nme].second; names += nme; names += '\n'; ++k; }
+    if (names_out && names_cap) { std::strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
+    return (int)k;
+}
 int bvh_ctx_synchronize(bvh_ctx* c) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return herr(hipStreamSynchronize(c->stream)); }
 
 int bvh_stage_extents(bvh_ctx* c, const void* d_tris, uint32_t n, void* d_prim_aabbs, void* d_scene_extent) {
@@ -248,6 +292,7 @@ int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_
     }
     hipStream_t s = c->stream;
     const bool prof = c->profiling;
+    struct Install { bool on; explicit Install(bvh_ctx* c) : on(c->kernel_profiling) { if (on) g_recorder = &c->recorder; } ~Install() { if (on) g_recorder = nullptr; } } install(c);
     uint32_t ploc_iters = 0;
     if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
     // E: CalculateSceneExtents (token CalculateCentroidExtentsTime).  The sort's bookkeeping is cleared here so that the
@@ -338,5 +383,9 @@ int bvh_dev_upload(bvh_ctx* c, void* d_dst, const void* h_src, uint64_t bytes) {
 int bvh_dev_download(bvh_ctx* c, void* h_dst, const void* d_src, uint64_t bytes) {
     if (!c) return BVH_E_INVALID_ARG; Bind b(c->device);
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream)); return herr(hipStreamSynchronize(c->stream)); }
+
+int bvh_dev_copy(bvh_ctx* c, void* d_dst, const void* d_src, uint64_t bytes) {   // asynchronous, ordered on the ctx's stream
+    if (!c) return BVH_E_INVALID_ARG; Bind b(c->device);
+    return herr(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream)); }
 
 } // extern "C"

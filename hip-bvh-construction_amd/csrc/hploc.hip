@@ -155,16 +155,16 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_primref* __restric
 
 void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,
                            uint32_t* d_cluster_idx, uint32_t* d_parent) {
-    hipLaunchKernelGGL(k_setup_clusters, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_svals,
-                       (bvh_primref*)d_leaves, d_cluster_idx, d_parent, n);
+    { KernelScope ks(s, "k_setup_clusters"); hipLaunchKernelGGL(k_setup_clusters, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_svals,
+                       (bvh_primref*)d_leaves, d_cluster_idx, d_parent, n); }
 }
 
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, uint32_t* d_cluster_idx, uint32_t* d_parent, uint32_t* d_counter) {
     hipMemsetAsync(d_counter, 0, sizeof(u32), s);
     launch_setup_clusters(s, d_boxes, d_svals, n, d_leaves, d_cluster_idx, d_parent);
-    hipLaunchKernelGGL(k_hploc, dim3((n + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_primref*)d_leaves, d_skeys,
-                       (bvh2_node*)d_nodes, d_cluster_idx, d_parent, d_counter, n);
+    { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((n + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_primref*)d_leaves, d_skeys,
+                       (bvh2_node*)d_nodes, d_cluster_idx, d_parent, d_counter, n); }
 }
 
 } // namespace bvh

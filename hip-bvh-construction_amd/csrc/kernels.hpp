@@ -5,6 +5,20 @@
 
 namespace bvh {
 
+// Optional per-kernel timing (bvh_ctx_set_profiling(ctx, 2)): launchers wrap each kernel launch in a KernelScope; when a
+// recorder is installed for the calling thread it brackets the launch with two hipEvents on the launch stream.
+struct KernelRecorder {
+    virtual void begin(hipStream_t s, const char* name) = 0;
+    virtual void end(hipStream_t s) = 0;
+    virtual ~KernelRecorder() {}
+};
+extern thread_local KernelRecorder* g_recorder;
+struct KernelScope {
+    hipStream_t s; bool on;
+    KernelScope(hipStream_t stream, const char* name) : s(stream), on(g_recorder != nullptr) { if (on) g_recorder->begin(s, name); }
+    ~KernelScope() { if (on) g_recorder->end(s); }
+};
+
 constexpr int EM_BLOCK = 256;
 
 // ---- stage E / M (stage_em.hip)

@@ -132,16 +132,16 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_sk
                         void* d_nodes, uint64_t* d_slots, uint32_t* d_root) {
     hipMemsetAsync(d_slots, 0xFF, (size_t)n * sizeof(u64), s);
     const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    hipLaunchKernelGGL(k_lbvh_single, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
-                       (bvh2_node*)d_nodes, d_slots, d_root, n);
+    { KernelScope ks(s, "k_lbvh_single"); hipLaunchKernelGGL(k_lbvh_single, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
+                       (bvh2_node*)d_nodes, d_slots, d_root, n); }
 }
 
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent, uint32_t* d_flags) {
     hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(u32), s);
     const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n);
-    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n);
+    { KernelScope ks(s, "k_karras"); hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n); }
+    { KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n); }
 }
 
 } // namespace bvh

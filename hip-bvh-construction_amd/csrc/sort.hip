@@ -171,6 +171,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
     }
 }
 
+__global__ void k_iota(u32* __restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 size_t sort_status_bytes(uint32_t n) { return (size_t)SORT_MAX_PASSES * sort_tiles(n) * SORT_RADIX * sizeof(u32); }
 
 void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n) {
@@ -185,6 +190,7 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
     if (passes <= 0) {   // nothing to sort on: identity permutation
         hipMemcpyAsync(keys_out, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
         if (vals_in) hipMemcpyAsync(vals_out, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        else hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, vals_out, n);
         return;
     }
     const u32 tiles = sort_tiles(n);
@@ -192,7 +198,7 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
         const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
         hipLaunchKernelGGL(k_hist, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
-    hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist);
+    { KernelScope ks(s, "k_scan_hist"); hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist); }
     const u32* kin = keys_in; const u32* vin = vals_in;
     for (int p = 0; p < passes; ++p) {
         const bool to_out = ((passes - 1 - p) % 2) == 0;          // last pass lands in the caller's output
@@ -202,6 +208,7 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
         const int w = (end_bit - sh) < SORT_BITS ? (end_bit - sh) : SORT_BITS;
         const u32 mask = (1u << w) - 1u;
         u32* st = sc.status + (size_t)p * tiles * SORT_RADIX;
+        KernelScope ks(s, "k_onesweep");
         if (vin == nullptr) hipLaunchKernelGGL(k_onesweep<true>,  dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p);
         else                hipLaunchKernelGGL(k_onesweep<false>, dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p);
         kin = kout; vin = vout;

@@ -197,12 +197,13 @@ static inline int em_grid(u32 n) {
 
 void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene) {
     hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
-    hipLaunchKernelGGL(k_extents, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+    { KernelScope ks(s, "k_extents"); hipLaunchKernelGGL(k_extents, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n); }
 }
 
 void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
                    u32* d_hist, int hist_bits, int passes) {
     const dim3 g(em_grid(n)), b(EM_BLOCK);
+    KernelScope ks(s, "k_morton");
     if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
     else if (d_hist && hist_bits == 10) hipLaunchKernelGGL(k_morton<10>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
     else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0);

@@ -57,7 +57,12 @@ typedef struct {
     uint32_t reserved;
     uint64_t bytes_algorithmic;        /* DESIGN.md "algorithmic bytes" for this build (n x per-prim figure) */
 } bvh_timings;
-int  bvh_ctx_set_profiling(bvh_ctx* ctx, int enabled);
+/* level 0: no events (bvh_build fully asynchronous where it can be); 1: one event per stage (the reference's Timer tokens);
+ * 2: additionally one event pair around every kernel launch, summed by bvh_ctx_kernel_times. */
+int  bvh_ctx_set_profiling(bvh_ctx* ctx, int level);
+/* Per-kernel HIP-event times accumulated since the last bvh_ctx_set_profiling(ctx, 2): returns the number of distinct
+ * kernels k; names_out receives k '\n'-separated names, ms_out[k] summed milliseconds, count_out[k] launch counts. */
+int  bvh_ctx_kernel_times(bvh_ctx* ctx, char* names_out, uint32_t names_cap, float* ms_out, uint32_t* count_out, uint32_t max_kernels);
 
 /* Result of a build.  All pointers are device pointers owned by the ctx; they stay valid until the next
  * bvh_build on the same ctx or bvh_ctx_destroy.  Mirrors the public members of the reference builders
@@ -127,6 +132,7 @@ int  bvh_dev_alloc(bvh_ctx* ctx, uint64_t bytes, void** out);
 int  bvh_dev_free(bvh_ctx* ctx, void* p);
 int  bvh_dev_upload(bvh_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
 int  bvh_dev_download(bvh_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+int  bvh_dev_copy(bvh_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device->device, asynchronous on the ctx's stream */
 
 const char* bvh_version(void);
 

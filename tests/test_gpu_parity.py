@@ -1,0 +1,139 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for keys / sort / LBVH node arrays / PLOC++ node arrays; HPLOC (schedule-dependent node numbering, as in the
+reference) identical canonical topology + SAH within 1e-4 relative (north_star tolerance)."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+SAH_RTOL = 1e-4   # BASELINE.json north_star: "match SAH cost within 1e-4 for PLOC variants"
+
+
+def meshes(pkg):
+    mg = pkg.meshgen
+    return {
+        "uniform_2": mg.uniform(2, 5), "uniform_3": mg.uniform(3, 6), "uniform_33": mg.uniform(33, 7), "uniform_65": mg.uniform(65, 8),
+        "uniform_1000": mg.uniform(1000, 9), "uniform_4097": mg.uniform(4097, 10), "uniform_50k": mg.uniform(50_000, 11),
+        "probe_5k": mg.probe_mesh(5000), "bunny_150k": mg.bunny_like(150_000, 2), "sponza_262k": mg.sponza_like(262_144, 3),
+        "dups_3000": np.repeat(mg.uniform(300, 12), 10), "flat_2000": _flat(mg.uniform(2000, 13)),
+    }
+
+
+def _flat(t):
+    t = t.copy()
+    for v in ("v1", "v2", "v3"):
+        t[v][:, 2] = 0.25
+    return t
+
+
+@pytest.fixture(scope="module")
+def cases(pkg):
+    return meshes(pkg)
+
+
+def _dev(ctx, a):
+    return ctx.upload(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("name", ["uniform_2", "uniform_33", "uniform_1000", "uniform_50k", "bunny_150k", "sponza_262k", "dups_3000", "flat_2000"])
+def test_stage_extents_and_morton(pkg, orc, ctx, cases, name):
+    tris = cases[name]; n = len(tris)
+    L = pkg.lib()
+    d_tris = _dev(ctx, tris); d_box = ctx.alloc(n * 24); d_scene = ctx.alloc(32); d_keys = ctx.alloc(n * 4); d_vals = ctx.alloc(n * 4)
+    assert L.bvh_stage_extents(ctx.handle, d_tris.ptr, n, d_box.ptr, d_scene.ptr) == 0
+    assert L.bvh_stage_morton(ctx.handle, d_box.ptr, n, d_scene.ptr, d_keys.ptr, d_vals.ptr) == 0
+    boxes, scene = orc.prim_bounds(tris)
+    keys, vals = orc.morton_codes(boxes, scene)
+    assert d_box.download(pkg.AABB, n).tobytes() == boxes.tobytes()
+    assert d_scene.download(pkg.AABB, 1).tobytes() == scene.tobytes()
+    got = d_keys.download(np.uint32, n)
+    assert np.array_equal(got, keys), f"{np.count_nonzero(got != keys)} Morton keys differ"
+    assert np.array_equal(d_vals.download(np.uint32, n), vals)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (2, 32), (255, 32), (4096, 32), (4097, 32), (100_003, 32), (1_000_000, 32), (100_003, 30), (100_003, 13), (5000, 0)])
+def test_sort_pairs(pkg, orc, ctx, n, bits):
+    rng = np.random.default_rng(n * 31 + bits)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    if n > 1000:
+        keys[::7] = keys[3]            # heavy duplicates: stability matters
+    vals = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    L = pkg.lib()
+    dk, dv, ok, ov = _dev(ctx, keys), _dev(ctx, vals), ctx.alloc(n * 4), ctx.alloc(n * 4)
+    assert L.bvh_sort_pairs(ctx.handle, dk.ptr, dv.ptr, n, ok.ptr, ov.ptr, 0, bits) == 0
+    mask = np.uint32((1 << bits) - 1) if bits < 32 else np.uint32(0xFFFFFFFF)
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(ok.download(np.uint32, n), keys[order])
+    assert np.array_equal(ov.download(np.uint32, n), vals[order])
+    assert np.array_equal(dk.download(np.uint32, n), keys)      # src untouched
+    # (key, index) flavour
+    assert L.bvh_sort_pairs(ctx.handle, dk.ptr, None, n, ok.ptr, ov.ptr, 0, bits) == 0
+    assert np.array_equal(ov.download(np.uint32, n), order.astype(np.uint32))
+
+
+ALL = ["uniform_2", "uniform_3", "uniform_33", "uniform_65", "uniform_1000", "uniform_4097", "uniform_50k", "probe_5k", "bunny_150k",
+       "sponza_262k", "dups_3000", "flat_2000"]
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("algo", [0, 1])
+def test_lbvh_bit_exact(pkg, orc, ctx, cases, name, algo):
+    tris = cases[name]; n = len(tris)
+    b = pkg.BUILDERS[algo]().build(ctx, tris)
+    got = b.download()
+    ref = orc.build_tree(algo, tris)
+    assert np.array_equal(got["sorted_keys"], ref["skeys"])
+    assert np.array_equal(got["sorted_vals"], ref["svals"])
+    assert got["root"] == ref["root"]
+    assert got["nodes"].tobytes() == ref["nodes"].tobytes(), "Bvh2Node[2n-1] differs from the oracle"
+    assert orc.validate_bvh2(got["nodes"], None, got["root"], n, 0) == 0
+    assert abs(b.sah_cost() - orc.sah_bvh2(ref["nodes"], None, ref["root"], n, 0)[0]) <= 1e-9 * max(1.0, b.m_cost)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_ploc_bit_exact(pkg, orc, ctx, cases, name):
+    tris = cases[name]; n = len(tris)
+    b = pkg.PLOCNew().build(ctx, tris)
+    got = b.download()
+    ref = orc.build_tree(2, tris)
+    assert got["leaves"].tobytes() == ref["leaves"].tobytes()
+    assert orc.validate_bvh2(got["nodes"], got["leaves"], 0, n, 1) == 0
+    assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1)
+    assert got["nodes"].tobytes() == ref["nodes"].tobytes(), "deterministic numbering: node arrays must be identical"
+    assert b.timings.ploc_iterations == ref["stats"]["iterations"]
+    s_ref = orc.sah_bvh2(ref["nodes"], ref["leaves"], 0, n, 1)[0]
+    assert abs(b.sah_cost() - s_ref) <= SAH_RTOL * s_ref
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_hploc_topology_and_sah(pkg, orc, ctx, cases, name):
+    tris = cases[name]; n = len(tris)
+    b = pkg.HPLOC().build(ctx, tris)
+    got = b.download()
+    ref = orc.build_tree(3, tris)
+    assert got["leaves"].tobytes() == ref["leaves"].tobytes()
+    assert orc.validate_bvh2(got["nodes"], got["leaves"], 0, n, 1) == 0
+    s_ref = orc.sah_bvh2(ref["nodes"], ref["leaves"], 0, n, 1)[0]
+    s_got = orc.sah_bvh2(got["nodes"], got["leaves"], 0, n, 1)[0]
+    assert abs(s_got - s_ref) <= SAH_RTOL * s_ref
+    assert abs(b.sah_cost() - s_ref) <= SAH_RTOL * s_ref
+    assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1)
+
+
+def test_layout_adapter(pkg, orc, ctx, cases):
+    tris = cases["uniform_50k"]; n = len(tris)
+    b = pkg.HPLOC().build(ctx, tris)
+    got = b.download()
+    conv = b.to_lbvh_layout()
+    assert conv.tobytes() == orc.ploc_to_lbvh_layout(got["nodes"], got["leaves"]).tobytes()
+    assert orc.validate_bvh2(conv, None, 0, n, 0) == 0
+
+
+def test_repeat_builds_same_ctx(pkg, orc, ctx, cases):
+    """arena reuse: builds of different sizes / algorithms on one ctx do not leak state into each other"""
+    for name, algo in (("uniform_50k", 1), ("uniform_1000", 3), ("bunny_150k", 2), ("uniform_33", 0), ("uniform_50k", 3)):
+        tris = cases[name]; n = len(tris)
+        b = pkg.BUILDERS[algo]().build(ctx, tris); got = b.download(); ref = orc.build_tree(algo, tris)
+        assert orc.topology_hash(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == \
+               orc.topology_hash(ref["nodes"], ref["leaves"], ref["root"], n, ref["layout"])
