@@ -21,7 +21,7 @@ from . import meshgen  # noqa: F401
 from .meshgen import TRIANGLE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbvh_mi355x.so")
+LIB_PATH = os.environ.get("BVH_MI355X_LIB", os.path.join(_HERE, "libbvh_mi355x.so"))   # override: A/B builds of the same ABI
 
 AABB = np.dtype([("min", "<f4", 3), ("max", "<f4", 3)])
 BVH2_NODE = np.dtype([("left", "<u4"), ("right", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])

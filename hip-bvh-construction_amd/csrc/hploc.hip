@@ -3,29 +3,46 @@
 // Replaces SetupClusters + HPloc of the reference (src/HplocKernel.h:39-56, :66-81 findParent, :83-117
 // findNearestNeighbours, :126-190 mergeClusters, :192-218 load/storeIndices, :220-255 plocMerge, :257-315 HPloc; host
 // src/Hploc.cpp:83-121).  Output: Bvh2Node[n-1] (root = node 0) + PrimRef[n] leaves in Morton order.  The tree topology is
-// the reference's (threshold 16, <= 32 clusters per merge step, search radius 8, mutual nearest neighbours under the
-// {area bits, index} order); node numbering follows allocation order and is schedule dependent, as in the reference.
+// the reference's: the implicit LBVH hierarchy over the sorted {key,position} words decides WHICH ranges are merged, and
+// every range larger than 16 leaves (or the root) runs PLOC rounds on the <= 16 + 16 surviving clusters of its two children
+// (search radius 8, mutual nearest neighbours under the {area bits, slot} order, lower slot owns the merge) until <= 16
+// (root: 1) remain.
 //
-// The reference runs one wave32 per 32 leaves and keeps the 32-entry work list in LDS with implicit lock-step and a
-// conflicting-store compaction.  Here one wave64 walks 64 leaves; the work list of a merge task
-// lives in registers of lanes 0..31 and moves with cross-lane operations only (ds_bpermute / ds_permute / DPP) — no LDS
-// allocation, no barriers, no reliance on store conflict order.
+// How the work is organised here (MI355X-first, not the reference's per-leaf walker):
+//  * one thread per LBVH gap p (between sorted leaves p and p+1) computes that node's leaf range [L,R] straight from the
+//    keys (common-prefix search; Karras/Apetrei trees are the same tree).  Ranges of <= 16 leaves need no work at all —
+//    the reference walks them with two global atomics per node just to discover them.
+//  * only "big" nodes (range > 16, ~n/11 of them) take part in a dependency protocol: counter[p] reaches 3 when the node's
+//    own thread (contributing 3 - #big children) and each big child (contributing 1) have arrived; whoever completes the
+//    count runs the merge task.  ~2 agent-scope atomics per big node instead of 2 per node.
+//  * a merge task occupies one 32-lane half of a wave64: the work list (id, rep, box) lives in registers, neighbours come
+//    from DPP wave shifts, partners through ds_bpermute, compaction through ds_permute.  Two tasks run side by side in the
+//    two halves.  No LDS allocation, no barriers, no reliance on store conflict order.
+//  * SetupClusters is fused: a leaf's PrimRef record is written when the leaf is first loaded as a cluster (exactly once);
+//    untouched child ranges are implicit (cluster id = n-1 + position), so the cluster-id array needs no initialisation.
+//  * node allocation: the reference takes node indices from ONE global counter (:163-167); a single word sustains ~90
+//    returning atomics/us on MI355X (~23 ms for a 10 M build).  Here every cluster carries the sorted position of its first
+//    leaf ("rep"); lists stay ordered by rep, a merge keeps the lower partner's rep and retires the absorbed partner's rep
+//    r in [1,n) exactly once — node index r-1 is a bijection onto [0,n-1).  The final merge moves whatever occupies node 0 to
+//    its own natural slot so that the root is node 0, as the reference guarantees.  Numbering depends on the topology only.
 //
-// Hand-off between waves (possibly on different XCDs): cluster ids (cidx) and internal-node boxes written during the
-// launch are agent-scope write-through stores, read back with agent-scope loads; the wave drains its stores before the
-// agent-scope atomic exchange on parent[] that hands the finished range to the sibling's walker.
+// Hand-off between waves (possibly on different XCDs): survivors (cidx) and node boxes written during the launch are
+// agent-scope write-through stores read back with agent-scope loads; a wave drains its stores (s_waitcnt vmcnt(0)) before
+// the agent-scope atomic on counter[] that publishes a finished range.
+#include <cstdlib>
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace bvh {
 
-constexpr int HP_BLOCK = 64;       // one wave per workgroup
+constexpr int HP_BLOCK = 256;
 constexpr u32 HP_HALF = 16;        // WarpSize/2 of the reference's wave32 (src/HplocKernel.h:195,238)
 constexpr int HP_RADIUS = 8;       // PlocRadius, src/Common.h:595
 
+// SetupClusters (:39-56) as a stand-alone kernel — used by PLOC++ (ploc.hip); HPLOC fuses it (see above).
 __global__ __launch_bounds__(256) void k_setup_clusters(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals,
                                                         bvh_primref* __restrict__ leaves, u32* __restrict__ cidx,
-                                                        u32* __restrict__ parent, u32 n) {   // SetupClusters :39-56
+                                                        u32* __restrict__ parent, u32 n) {
     const u32 g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n) return;
     const u32 prim = svals[g];
@@ -37,118 +54,197 @@ __global__ __launch_bounds__(256) void k_setup_clusters(const bvh_aabb* __restri
     if (parent) parent[g] = INV;
 }
 
+__device__ __forceinline__ int clz64(u64 v) { return v ? __clzll((long long)v) : 64; }
+__device__ __forceinline__ float dpp_shl1(float v) {   // lane i <- lane i+1 (whole wave; DPP wave_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, true));   // bound_ctrl: lane 63 reads 0
+}
+__device__ __forceinline__ Box box_shl1(const Box& b) { return { dpp_shl1(b.lx), dpp_shl1(b.ly), dpp_shl1(b.lz), dpp_shl1(b.hx), dpp_shl1(b.hy), dpp_shl1(b.hz) }; }
 __device__ __forceinline__ Box shfl_box(const Box& b, int src) {
     return { __shfl(b.lx, src), __shfl(b.ly, src), __shfl(b.lz, src), __shfl(b.hx, src), __shfl(b.hy, src), __shfl(b.hz, src) };
-}
-__device__ __forceinline__ Box shfl_down_box(const Box& b, int d) {
-    return { __shfl_down(b.lx, d), __shfl_down(b.ly, d), __shfl_down(b.lz, d), __shfl_down(b.hx, d), __shfl_down(b.hy, d), __shfl_down(b.hz, d) };
 }
 // push semantics: lane l's value lands in lane dst(l)
 __device__ __forceinline__ u32 push_u32(int dst, u32 v) { return (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)v); }
 __device__ __forceinline__ float push_f32(int dst, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v))); }
 
-// One plocMerge (:220-255) for the range [tL, tR) split at tS, executed by the whole wave; slots = lanes 0..31.
-__device__ __forceinline__ void merge_task(u32 tL, u32 tS, u32 tR, bool final_, const bvh_primref* __restrict__ leaves,
-                                           bvh2_node* nodes, u32* cidx, u32* counter, u32 ni, int lane, u64 lt) {
-    // loadIndices (:192-206): the first min(len,16) ids of each child range; valid ones form a prefix
-    const u32 lenL = min(tS - tL, HP_HALF), lenR = min(tR - tS, HP_HALF);
-    u32 id = INV;
-    if (lane < 16) { if ((u32)lane < lenL) id = ld_agent(cidx + tL + lane); }
-    else if (lane < 32) { if ((u32)(lane - 16) < lenR) id = ld_agent(cidx + tS + (lane - 16)); }
-    const u64 vb = __ballot(id != INV);
-    const u32 nl = (u32)__popcll(vb & 0xFFFFull), nr = (u32)__popcll(vb & 0xFFFF0000ull);
-    const u32 loaded = nl + nr;
-    u32 cnt = loaded;
-    {   // left-pack: slot s < nl <- lane s ; slot s in [nl, cnt) <- lane 16 + (s - nl)
-        const int src = ((u32)lane < nl) ? lane : (int)(16 + (u32)lane - nl);
-        const u32 t = (u32)__shfl((int)id, src & 63);
-        id = ((u32)lane < cnt) ? t : INV;
-    }
-    Box b = box_empty();
-    if (id != INV) b = (id >= ni) ? box_load(&leaves[id - ni].aabb) : node_box_agent(nodes + id);   // :242-246
-    const u32 threshold = final_ ? 1u : HP_HALF;
-    while (cnt > threshold) {
-        // findNearestNeighbours (:83-117): key = {area bits, neighbour slot}; both directions evaluated from one area
-        u64 best = ~0ull;
-#pragma unroll
-        for (int r = 1; r <= HP_RADIUS; ++r) {
-            const Box nb = shfl_down_box(b, r);
-            const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
-            const u32 ab_left = (u32)__shfl_up((int)ab, r);
-            if ((u32)(lane + r) < cnt) { const u64 k = ((u64)ab << 32) | (u32)(lane + r); best = k < best ? k : best; }
-            if (lane >= r && (u32)lane < cnt) { const u64 k = ((u64)ab_left << 32) | (u32)(lane - r); best = k < best ? k : best; }
-        }
-        // mergeClusters (:126-190)
-        const int nbr = (int)((u32)best & 63u);
-        const u32 nbr_of_nbr = (u32)__shfl((int)(u32)best, nbr);
-        const bool in = (u32)lane < cnt;
-        const bool mutual = in && nbr_of_nbr == (u32)lane;
-        const bool merge = mutual && lane < nbr;
-        const bool absorbed = mutual && lane > nbr;
-        const u64 mm = __ballot(merge);
-        const u32 total = (u32)__popcll(mm);
-        u32 base = 0;
-        if (lane == 0) base = __hip_atomic_fetch_add(counter, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :163
-        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-        const u32 new_node = ni - base - total + (u32)__popcll(mm & lt);                                          // :165-167
-        const u32 id_nb = (u32)__shfl((int)id, nbr);
-        const Box bn = shfl_box(b, nbr);
-        if (merge) {
-            b = box_union(b, bn);
-            node_store_agent(nodes + new_node, id, id_nb, b);
-            id = new_node;
-        }
-        // compaction: survivors and merged clusters keep their order (:176-187, as "valid lanes write to their rank")
-        const bool keep = in && !absorbed;
-        const u64 km = __ballot(keep);
-        const u32 newcnt = (u32)__popcll(km);
-        const int dst = keep ? (int)__popcll(km & lt) : 63;    // lane 63 is never a slot: harmless sink
-        id = push_u32(dst, id);
-        b.lx = push_f32(dst, b.lx); b.ly = push_f32(dst, b.ly); b.lz = push_f32(dst, b.lz);
-        b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
-        if ((u32)lane >= newcnt) id = INV;
-        cnt = newcnt;
-    }
-    if ((u32)lane < loaded) st_agent(cidx + tL + lane, id);      // storeIndices (:208-218)
-}
+// cidx entry: {cluster id, rep}
+__device__ __forceinline__ u64 entry(u32 id, u32 rep) { return (u64)id | ((u64)rep << 32); }
 
-__global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_primref* __restrict__ leaves, const u32* __restrict__ skeys,
-                                                    bvh2_node* nodes, u32* cidx, u32* parent, u32* counter, u32 n) {
-    const int lane = threadIdx.x;
-    const u64 lt = (1ull << lane) - 1ull;
-    const u32 g = blockIdx.x * HP_BLOCK + (u32)lane;
+#ifndef HP_WAVES
+#define HP_WAVES 1
+#endif
+__global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+                                                    const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
+                                                    bvh2_node* nodes, u64* cidx, u64* ranges, u32* counter, u32* zero_parent, u32 n, int dbg) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
     const u32 ni = n - 1;
-    u32 L = g, R = g;                       // inclusive range
-    bool active = g < n;                    // covers every leaf (the reference under-launches when (n-1)%32==0, App. B)
-    while (__ballot(active)) {
-        u32 split = INV;
-        if (active) {
-            // findParent (:66-81) with inclusive R: hand over to the split at R (as left child) or at L-1 (as right child)
-            bool to_right;
-            if (L == 0) to_right = true;
-            else if (R == ni) to_right = false;
-            else to_right = (aug_key(skeys, R) ^ aug_key(skeys, R + 1)) < (aug_key(skeys, L - 1) ^ aug_key(skeys, L));
-            drain_stores();                 // the wave's node / cidx stores are in memory before the range is handed over
-            u32 prev;
-            if (to_right) {
-                prev = __hip_atomic_exchange(parent + R, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // :278
-                if (prev != INV) { split = R + 1; R = prev; }
-            } else {
-                prev = __hip_atomic_exchange(parent + (L - 1), R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :288
-                if (prev != INV) { split = L; L = prev; }
-            }
-            if (prev == INV) active = false;
+    u32 pc = blockIdx.x * HP_BLOCK + threadIdx.x;      // LBVH gap / node this lane currently speaks for
+    u32 L = 0, R = 0;
+    bool ready = false;
+
+    // ---- phase 1: range of node pc from the keys; dependency bookkeeping for big nodes ---------------------------------
+    // The block's key window [g0 - 256, g0 + 512] sits in LDS: almost every probe of the common-prefix searches lands there
+    // (a dependent L2 round trip per probe otherwise); only ranges reaching beyond the window probe global memory.
+    __shared__ u32 s_keys[HP_BLOCK * 3 + 1];
+    const int g0 = (int)(blockIdx.x * HP_BLOCK);
+    const int w0 = g0 - HP_BLOCK;
+    for (int k = threadIdx.x; k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : 0u; }
+    __syncthreads();
+    auto key_at = [&](int j) -> u64 {
+        const u32 k = ((u32)(j - w0) <= (u32)(HP_BLOCK * 3)) ? s_keys[j - w0] : skeys[j];
+        return ((u64)k << 32) | (u32)j;
+    };
+    if (pc < ni) {
+        const int p = (int)pc;
+        const u64 kp = key_at(p);
+        const int c0 = clz64(kp ^ key_at(p + 1));                               // common prefix length of the node
+        auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(key_at(j) ^ kp) >= c0; };
+        {   // leftmost leaf sharing the prefix (n < 2^30: int arithmetic cannot overflow)
+            int step = 1;
+            while (inside(p - step)) step <<= 1;
+            int lo = p - (step >> 1);                                           // known inside (step 1 -> p itself)
+            for (int t = step >> 2; t > 0; t >>= 1) if (inside(lo - t)) lo -= t;
+            L = (u32)lo;
         }
-        compiler_fence();
+        {   // rightmost
+            int step = 1;
+            while (inside(p + 1 + step)) step <<= 1;
+            int hi = p + 1 + (step >> 1);
+            for (int t = step >> 2; t > 0; t >>= 1) if (inside(hi + t)) hi += t;
+            R = (u32)hi;
+        }
         const u32 size = R - L + 1;
-        const bool final_ = active && size == n;
-        u64 todo = __ballot((active && size > HP_HALF) || final_);                                           // :305
-        while (todo) {
-            const int owner = __ffsll((unsigned long long)todo) - 1;
-            const u32 tL = (u32)__shfl((int)L, owner), tS = (u32)__shfl((int)split, owner), tR = (u32)__shfl((int)R, owner) + 1u;
-            const bool tF = __shfl((int)final_, owner) != 0;
-            merge_task(tL, tS, tR, tF, leaves, nodes, cidx, counter, ni, lane, lt);
-            todo &= todo - 1;
+        if (size > HP_HALF || size == n) {                                       // :303-305 (size > 16 or root)
+            const u32 e = ((pc - L + 1) > HP_HALF ? 1u : 0u) + ((R - pc) > HP_HALF ? 1u : 0u);
+            if (e == 0) ready = true;
+            else {
+                st_agent(ranges + pc, (u64)L | ((u64)R << 32));
+                drain_stores();
+                const u32 old = __hip_atomic_fetch_add(counter + pc, 3u - e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = (old + (3u - e)) == 3u;
+            }
+        }
+    }
+
+    if (dbg == 1) return;
+    // ---- phase 2: run ready merge tasks, two per pass (one per 32-lane half), then climb ----------------------------------
+    while (true) {
+        const u64 rm = __ballot(ready);
+        if (!rm) break;
+        const int ownA = __ffsll((unsigned long long)rm) - 1;
+        const u64 rm2 = rm & (rm - 1);
+        const int ownB = rm2 ? __ffsll((unsigned long long)rm2) - 1 : -1;
+        const int own = half ? ownB : ownA;
+        const bool have = own >= 0;
+        const int osrc = have ? own : 0;
+        const u32 tL = (u32)__shfl((int)L, osrc), tR = (u32)__shfl((int)R, osrc), tP = (u32)__shfl((int)pc, osrc);
+        const bool final_ = have && tL == 0 && tR == ni;
+
+        // -- loadIndices (:192-206): slots 0..15 <- left child, 16..31 <- right child; small children are implicit leaves
+        const bool is_left = slot < 16;
+        const u32 s = (u32)(slot & 15);
+        const u32 c_start = is_left ? tL : tP + 1, c_len = is_left ? (tP - tL + 1) : (tR - tP);
+        u32 id = INV, rep = INV;
+        if (have) {
+            if (c_len > HP_HALF) { const u64 e = ld_agent(cidx + c_start + s); id = (u32)e; rep = (u32)(e >> 32); }
+            else if (s < c_len) { rep = c_start + s; id = ni + rep; }
+        }
+        const u32 vb = (u32)(__ballot(id != INV) >> hbase);
+        const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
+        u32 cnt = nl + nr;
+        {   // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
+            const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
+            const u32 ti = (u32)__shfl((int)id, src), tr = (u32)__shfl((int)rep, src);
+            id = ((u32)slot < cnt) ? ti : INV; rep = tr;
+        }
+        Box b = box_empty();
+        if (id != INV) {
+            if (id >= ni) {   // first (and only) load of this leaf: fused SetupClusters (:44-47)
+                const u32 prim = svals[rep];
+                b = box_load(boxes + prim);
+                float* f = reinterpret_cast<float*>(leaves + rep);
+                reinterpret_cast<u32*>(f)[0] = prim;
+                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+            } else b = node_box_agent(nodes + id);                                                  // :242-246
+        }
+        const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
+        while (__ballot(have && cnt > threshold)) {
+            const bool act = have && cnt > threshold;
+            // findNearestNeighbours (:83-117): key = {area bits, neighbour slot}; each pair's area is evaluated once
+            u64 best = ~0ull;
+            Box nb = b;
+#pragma unroll
+            for (int r = 1; r <= HP_RADIUS; ++r) {
+                nb = box_shl1(nb);                                               // box of slot + r
+                const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
+                const u32 ab_left = (u32)__shfl_up((int)ab, r);                  // area(slot - r, slot)
+                if ((u32)(slot + r) < cnt) { const u64 k = ((u64)ab << 32) | (u32)(slot + r); best = k < best ? k : best; }
+                if (slot >= r && (u32)slot < cnt) { const u64 k = ((u64)ab_left << 32) | (u32)(slot - r); best = k < best ? k : best; }
+            }
+            // mergeClusters (:126-190)
+            const int nbr = (int)((u32)best & 31u);
+            const int nsrc = hbase + nbr;
+            const u32 nbr_of_nbr = (u32)__shfl((int)(u32)best, nsrc);
+            const bool in = act && (u32)slot < cnt;
+            const bool mutual = in && nbr_of_nbr == (u32)slot;
+            const bool merge = mutual && slot < nbr;
+            const bool absorbed = mutual && slot > nbr;
+            const u32 id_nb = (u32)__shfl((int)id, nsrc);
+            const u32 rep_nb = (u32)__shfl((int)rep, nsrc);
+            const Box bn = shfl_box(b, nsrc);
+            if (merge) {
+                b = box_union(b, bn);
+                u32 at = rep_nb - 1u;                            // the absorbed partner's rep is retired here, once
+                u32 l = id, r = id_nb;
+                if (final_ && cnt == 2u && at != 0u) {
+                    // the root must be node 0 (:165-167 makes the last allocation 0): move node 0's occupant to the root's
+                    // natural slot and re-point its parent
+                    const u64* q0 = reinterpret_cast<const u64*>(nodes);
+                    u64* qs = reinterpret_cast<u64*>(nodes + at);
+                    const u64 w0 = ld_agent(q0 + 0), w1 = ld_agent(q0 + 1), w2 = ld_agent(q0 + 2), w3 = ld_agent(q0 + 3);
+                    st_agent(qs + 0, w0); st_agent(qs + 1, w1); st_agent(qs + 2, w2); st_agent(qs + 3, w3);
+                    if (l == 0u) l = at;
+                    else if (r == 0u) r = at;
+                    else {
+                        const u32 pw = ld_agent(zero_parent);
+                        st_agent(reinterpret_cast<u32*>(nodes + (pw >> 1)) + (pw & 1u), at);
+                    }
+                    at = 0u;
+                } else if (l == 0u || r == 0u) st_agent(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
+                node_store_agent(nodes + at, l, r, b);
+                id = at;
+            }
+            // compaction: survivors and merged clusters keep their order (:176-187 as "valid slots write to their rank").
+            // Slot 31 of a half is never a destination after a round (>= 1 merge), so it serves as the sink.
+            const bool keep = in && !absorbed;
+            const u32 kh = (u32)(__ballot(keep) >> hbase);
+            const u32 newcnt = (u32)__popc(kh);
+            const int dst = act ? (hbase + (keep ? (int)__popc(kh & ((1u << slot) - 1u)) : 31)) : lane;
+            id = push_u32(dst, id); rep = push_u32(dst, rep);
+            b.lx = push_f32(dst, b.lx); b.ly = push_f32(dst, b.ly); b.lz = push_f32(dst, b.lz);
+            b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
+            if (act) { if ((u32)slot >= newcnt) id = INV; cnt = newcnt; }
+        }
+        // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
+        if (have && !final_ && slot < 16) st_agent(cidx + tL + slot, entry(id, rep));
+
+        // -- the owners hand their finished range to the parent node
+        if (ready && (lane == ownA || lane == ownB)) {
+            ready = false;
+            if (!(L == 0 && R == ni)) {
+                // findParent (:66-81): the boundary gap with the longer common prefix (smaller xor) is the parent
+                u32 q;
+                if (L == 0) q = R;
+                else if (R == ni) q = L - 1;
+                else q = ((aug_key(skeys, R) ^ aug_key(skeys, R + 1)) < (aug_key(skeys, L - 1) ^ aug_key(skeys, L))) ? R : L - 1;
+                drain_stores();                 // the wave's node / survivor stores are in memory before the count moves
+                const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1u == 3u) {
+                    compiler_fence();
+                    const u64 rg = ld_agent(ranges + q);
+                    pc = q; L = (u32)rg; R = (u32)(rg >> 32); ready = true;
+                }
+            }
         }
     }
 }
@@ -160,11 +256,11 @@ void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d
 }
 
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                  void* d_nodes, void* d_leaves, uint32_t* d_cluster_idx, uint32_t* d_parent, uint32_t* d_counter) {
-    hipMemsetAsync(d_counter, 0, sizeof(u32), s);
-    launch_setup_clusters(s, d_boxes, d_svals, n, d_leaves, d_cluster_idx, d_parent);
-    { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((n + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_primref*)d_leaves, d_skeys,
-                       (bvh2_node*)d_nodes, d_cluster_idx, d_parent, d_counter, n); }
+                  void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent) {
+    hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
+    const u32 gaps = n - 1;
+    { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
+                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, n, getenv("BVH_HPLOC_DEBUG") ? atoi(getenv("BVH_HPLOC_DEBUG")) : 0); }
 }
 
 } // namespace bvh

@@ -55,8 +55,8 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_sk
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                  void* d_nodes, void* d_leaves, uint32_t* d_cluster_idx /*u32[n]*/, uint32_t* d_parent /*u32[n]*/,
-                  uint32_t* d_counter /*u32[1]*/);
+                  void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx /*u64[n] {id,rep}*/, uint64_t* d_ranges /*u64[n]*/,
+                  uint32_t* d_counter /*u32[n]*/, uint32_t* d_zero_parent /*u32[1]*/);
 struct PlocScratch {
     uint32_t* ids0;          // u32[n]
     uint32_t* ids1;          // u32[n]
