@@ -289,4 +289,6 @@ class HPLOC(_Builder):
     ALGO = ALGO_HPLOC
 
 
+from .batched import BatchedBuildInput, BatchedBvhBuilder, shard  # noqa: E402,F401
+
 BUILDERS = {ALGO_TWOPASS: TwoPassLbvh, ALGO_SINGLEPASS: SinglePassLbvh, ALGO_PLOCPP: PLOCNew, ALGO_HPLOC: HPLOC}

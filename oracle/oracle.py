@@ -237,3 +237,70 @@ def ref_utility():
         L.ref_sizeof.argtypes = [C.c_int]; L.ref_sizeof.restype = u32
         _ref = L
     return _ref
+
+
+# ---- the reference's own device kernels on the GPU (oracle/_ref/*.co driven by oracle/ref_driver.cpp), when built ------
+_drv = {}
+
+
+def ref_driver(nofma: bool = False):
+    """Loads oracle/_ref/libref_driver.so and the reference's compiled kernels; None when not built / no GPU."""
+    key = bool(nofma)
+    if key in _drv:
+        return _drv[key]
+    if not os.path.exists(REF_DRIVER):
+        return None
+    L = C.CDLL(REF_DRIVER)
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.refdrv_error.restype = C.c_char_p
+    L.refdrv_init.argtypes = [C.c_char_p, C.c_int]
+    L.refdrv_morton.argtypes = [vp, u32, vp, vp, vp]
+    L.refdrv_lbvh_single.argtypes = [vp, u32, vp, vp, vp, C.POINTER(u32)]
+    L.refdrv_lbvh_two.argtypes = [vp, u32, vp, vp, vp]
+    L.refdrv_hploc.argtypes = [vp, u32, vp, vp, vp, vp, C.POINTER(u32), C.c_int]
+    rc = L.refdrv_init(os.path.join(_HERE, "_ref").encode(), int(nofma))
+    if rc != 0:
+        raise RuntimeError("refdrv_init: " + L.refdrv_error().decode())
+    _drv[key] = L
+    return L
+
+
+def _rc(L, rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {L.refdrv_error().decode()}")
+
+
+def _reinit(L, nofma):
+    # one process-wide set of loaded modules: re-load when switching flavour
+    rc = L.refdrv_init(os.path.join(_HERE, "_ref").encode(), int(nofma))
+    if rc != 0:
+        raise RuntimeError("refdrv_init: " + L.refdrv_error().decode())
+
+
+def ref_morton(boxes, scene, nofma=False):
+    L = ref_driver(nofma); _reinit(L, nofma); n = boxes.shape[0]
+    keys = np.empty(n, dtype=np.uint32); vals = np.empty(n, dtype=np.uint32)
+    _rc(L, L.refdrv_morton(boxes.ctypes.data, n, scene.ctypes.data, keys.ctypes.data, vals.ctypes.data), "refdrv_morton")
+    return keys, vals
+
+
+def ref_lbvh_single(tris, skeys, svals, nofma=False):
+    L = ref_driver(nofma); _reinit(L, nofma); n = tris.shape[0]
+    nodes = np.zeros(2 * n - 1, dtype=BVH2_NODE); root = C.c_uint32()
+    _rc(L, L.refdrv_lbvh_single(tris.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, C.byref(root)), "refdrv_lbvh_single")
+    return nodes, int(root.value)
+
+
+def ref_lbvh_two(tris, skeys, svals, nofma=False):
+    L = ref_driver(nofma); _reinit(L, nofma); n = tris.shape[0]
+    refs = primrefs(tris)
+    nodes = np.zeros(2 * n - 1, dtype=BVH2_NODE)
+    _rc(L, L.refdrv_lbvh_two(refs.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data), "refdrv_lbvh_two")
+    return nodes
+
+
+def ref_hploc(boxes, skeys, svals, nofma=False, cover_all=False):
+    L = ref_driver(nofma); _reinit(L, nofma); n = boxes.shape[0]
+    nodes = np.zeros(max(n - 1, 1), dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); merged = C.c_uint32()
+    _rc(L, L.refdrv_hploc(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, C.byref(merged), int(cover_all)), "refdrv_hploc")
+    return nodes[: n - 1], leaves, int(merged.value)

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.
+
+  step 1 (dev container, needs /root/reference):  python tools/make_golden.py meshes
+      Cornell-box triangle lists exactly as the reference's MeshLoader::loadScene (src/Utility.cpp:614-760, run from
+      oracle/_ref/libref_utility.so = the reference's unmodified Utility.cpp) emits them, as raw little-endian f32 (n x 9).
+  step 2 (GPU box, through gpurun):  python tools/make_golden.py reference gpurun_out/golden_reference.json
+      Outputs of the REFERENCE's own kernels (oracle/_ref/*.co via oracle/ref_driver.cpp) on the golden meshes: FNV-1a of the
+      Morton keys and of the LBVH node arrays, single-pass root index, HPLOC canonical topology hash / SAH (kernel built
+      with FP contraction off), plus the reference's Utility::calculateLbvhCost of its own LBVH tree.
+      Copy the JSON to tests/golden/reference_outputs.json.
+Fixtures are data (inputs and expected outputs); no reference source text is stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CORNELL = {"cornell32": "cornellBox", "cornell82": "untitled", "cornell382": "xyz"}
+
+
+def golden_meshes(pkg):
+    mg = pkg.meshgen
+    out = {name: mg.load_tri(os.path.join(GOLDEN, name + ".tri")) for name in CORNELL}
+    out["uniform5000_s77"] = mg.uniform(5000, 77)
+    out["sponza8000_s3"] = mg.sponza_like(8000, 3)
+    out["bunny6000_s2"] = mg.bunny_like(6000, 2)
+    out["probe5000"] = mg.probe_mesh(5000)
+    return out
+
+
+def make_meshes():
+    import oracle as orc
+    R = orc.ref_utility()
+    if R is None:
+        raise SystemExit("oracle/_ref/libref_utility.so missing: run make -C oracle ref in the dev container")
+    base = "/root/reference/src/Meshes/cornellbox/"
+    for out_name, obj in CORNELL.items():
+        path = (base + obj + ".obj").encode()
+        n = R.ref_loadScene(path, base.encode(), None, 0)
+        t = np.zeros(n, dtype=orc.TRIANGLE)
+        R.ref_loadScene(path, base.encode(), t.ctypes.data, n)
+        raw = np.stack([t["v1"], t["v2"], t["v3"]], axis=1).astype("<f4")
+        raw.tofile(os.path.join(GOLDEN, out_name + ".tri"))
+        print(out_name, n, "triangles")
+
+
+def make_reference(out_path):
+    import bvh_pkg
+    import oracle as orc
+    pkg = bvh_pkg.load()
+    R = orc.ref_utility()
+    res = {}
+    for name, tris in golden_meshes(pkg).items():
+        n = len(tris)
+        boxes, scene = orc.prim_bounds(tris)            # min/max only: order independent, identical on any correct implementation
+        keys, _ = orc.ref_morton(boxes, scene)
+        order = np.argsort(keys, kind="stable")
+        skeys, svals = keys[order], order.astype(np.uint32)
+        n1, root1 = orc.ref_lbvh_single(tris, skeys, svals)
+        n2 = orc.ref_lbvh_two(tris, skeys, svals)
+        cover = (n - 1) % 32 == 0
+        hn, hl, merged = orc.ref_hploc(boxes, skeys, svals, nofma=True, cover_all=cover)
+        entry = {
+            "n": n, "keys_fnv": "%016x" % orc.fnv1a(keys), "sorted_key_first": int(skeys[0]), "sorted_key_last": int(skeys[-1]),
+            "duplicate_keys": int(n - len(np.unique(keys))),
+            "lbvh_single_fnv": "%016x" % orc.fnv1a(n1), "lbvh_single_root": root1,
+            "lbvh_two_fnv": "%016x" % orc.fnv1a(n2),
+            "lbvh_sah_f64": orc.sah_bvh2(n1, None, root1, n, 0)[0],
+            "hploc_topology": "%016x" % orc.topology_hash(hn, hl, 0, n, 1), "hploc_sah_f64": orc.sah_bvh2(hn, hl, 0, n, 1)[0],
+            "hploc_merged": merged,
+        }
+        if R is not None:
+            entry["ref_utility_lbvh_cost_f32"] = float(R.ref_calculateLbvhCost(n1.ctypes.data, root1, n, n - 1))
+        res[name] = entry
+        print(name, entry)
+    json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 2 and sys.argv[1] == "meshes":
+        make_meshes()
+    elif len(sys.argv) >= 3 and sys.argv[1] == "reference":
+        make_reference(sys.argv[2])
+    else:
+        raise SystemExit(__doc__)
