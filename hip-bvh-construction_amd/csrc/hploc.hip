@@ -170,21 +170,23 @@ __global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __
         const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
         while (__ballot(have && cnt > threshold)) {
             const bool act = have && cnt > threshold;
-            // findNearestNeighbours (:83-117): key = {area bits, neighbour slot}; each pair's area is evaluated once
-            u64 best = ~0ull;
+            // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
+            // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
+            // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
+            u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
             Box nb = b;
 #pragma unroll
             for (int r = 1; r <= HP_RADIUS; ++r) {
                 nb = box_shl1(nb);                                               // box of slot + r
                 const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
                 const u32 ab_left = (u32)__shfl_up((int)ab, r);                  // area(slot - r, slot)
-                if ((u32)(slot + r) < cnt) { const u64 k = ((u64)ab << 32) | (u32)(slot + r); best = k < best ? k : best; }
-                if (slot >= r && (u32)slot < cnt) { const u64 k = ((u64)ab_left << 32) | (u32)(slot - r); best = k < best ? k : best; }
+                if ((u32)(slot + r) < cnt && ab < abR) { abR = ab; idR = slot + r; }
+                if (slot >= r && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - r; }
             }
             // mergeClusters (:126-190)
-            const int nbr = (int)((u32)best & 31u);
+            const int nbr = (abL <= abR) ? idL : idR;
             const int nsrc = hbase + nbr;
-            const u32 nbr_of_nbr = (u32)__shfl((int)(u32)best, nsrc);
+            const u32 nbr_of_nbr = (u32)__shfl(nbr, nsrc);
             const bool in = act && (u32)slot < cnt;
             const bool mutual = in && nbr_of_nbr == (u32)slot;
             const bool merge = mutual && slot < nbr;

@@ -14,6 +14,7 @@
 //    relaxed agent-scope atomics: the value is its own flag, so no fence is needed across XCDs.
 //  * tile ids come from an atomic ticket, so a tile only ever waits on tiles that are already running.
 //  * pairs are staged through LDS in their tile-sorted order so that global writes are runs of consecutive addresses.
+#include <cstdlib>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -61,7 +62,7 @@ template <bool IOTA>
 __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                          u32* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
                                                          int shift, u32 digit_mask, const u32* __restrict__ ghist,
-                                                         u32* status, u32* tile_counter) {
+                                                         u32* status, u32* tile_counter, int dbg) {
     constexpr int NW = SORT_BLOCK / WAVE;
     __shared__ u32 s_whist[NW][SORT_RADIX];
     __shared__ u32 s_binoff[SORT_RADIX];
@@ -133,18 +134,30 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
         for (int w = 0; w < NW; ++w) if (w < wave) wbase += s_wsum[w];
         s_binoff[tid] = wbase + inc - total;
     }
-    // ---- decoupled look-back for digit `tid`
+    // ---- decoupled look-back for digit `tid`: LB_WINDOW predecessors are fetched per step (independent loads in flight)
+    // so that a walk over k tiles costs ~k/LB_WINDOW memory round trips instead of k
     {
         u32 excl = 0;
-        if (tile > 0) {
+        if (tile > 0 && !(dbg & 1)) {
+            constexpr int LB_WINDOW = 8;
             int prev = (int)tile - 1;
-            while (true) {
-                const u32 st = ld_agent(&status[(size_t)prev * SORT_RADIX + tid]);
-                const u32 flag = st >> 30;
-                if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
-                excl += st & ST_MASK;
-                if (flag == 2) break;
-                --prev;
+            bool done = false;
+            while (!done) {
+                u32 st[LB_WINDOW];
+#pragma unroll
+                for (int w = 0; w < LB_WINDOW; ++w)
+                    st[w] = (prev - w >= 0) ? ld_agent(&status[(size_t)(prev - w) * SORT_RADIX + tid]) : (ST_INCL | 0u);
+                int used = 0;
+#pragma unroll
+                for (int w = 0; w < LB_WINDOW; ++w) {
+                    if (done || used != w) continue;
+                    const u32 flag = st[w] >> 30;
+                    if (flag == 0) continue;                 // not published yet: re-poll from here
+                    excl += st[w] & ST_MASK; used = w + 1;
+                    if (flag == 2) done = true;
+                }
+                prev -= used;
+                if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
             }
             st_agent(&status[(size_t)tile * SORT_RADIX + tid], ST_INCL | (excl + total));
         }
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
         const u32 p = (u32)(k * SORT_BLOCK + tid);
         if (p < valid) {
             const u32 kk = s_keys[p];
-            const u32 dst = s_gbase[(kk >> shift) & digit_mask] + p;
+            const u32 dst = (dbg & 2) ? base + p : s_gbase[(kk >> shift) & digit_mask] + p;
             keys_out[dst] = kk; vals_out[dst] = s_vals[p];
         }
     }
@@ -199,6 +212,7 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
         hipLaunchKernelGGL(k_hist, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
     { KernelScope ks(s, "k_scan_hist"); hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist); }
+    const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;
     const u32* kin = keys_in; const u32* vin = vals_in;
     for (int p = 0; p < passes; ++p) {
         const bool to_out = ((passes - 1 - p) % 2) == 0;          // last pass lands in the caller's output
@@ -209,8 +223,8 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
         const u32 mask = (1u << w) - 1u;
         u32* st = sc.status + (size_t)p * tiles * SORT_RADIX;
         KernelScope ks(s, "k_onesweep");
-        if (vin == nullptr) hipLaunchKernelGGL(k_onesweep<true>,  dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p);
-        else                hipLaunchKernelGGL(k_onesweep<false>, dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p);
+        if (vin == nullptr) hipLaunchKernelGGL(k_onesweep<true>,  dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p, dbg);
+        else                hipLaunchKernelGGL(k_onesweep<false>, dim3(tiles), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, n, sh, mask, sc.hist + p * SORT_RADIX, st, sc.counters + p, dbg);
         kin = kout; vin = vout;
     }
 }
