@@ -33,6 +33,10 @@ KERNEL_BYTES_PER_PRIM = {
     "k_onesweep": 17.0,           # per pass: R 8 + W 8 (+ hist R 4 amortised over 4 passes)
     "k_setup_clusters": 64.0,     # R val 4 + gather Aabb 24 + W PrimRef 28 + W nodeIdx 4 + W parentIdx 4
     "k_hploc": 134.0,             # keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32
+    "k_hp_level": 114.0,          # level-synchronous variant, all 62 level launches as one group: the same minus keys (4, read by
+                                  # k_hp_plan) and the parent exchange (16, replaced by launch order)
+    "k_hp_plan": 8.7,             # R key 4 + W level key 4 + W range 8 per big node (~0.09 / prim)
+    "k_hist": 4.0,
     "k_lbvh_single": 224.0,
     "k_karras": 100.0, "k_refit": 88.0,
     "k_ploc_iter": 190.0,         # summed over all iterations
@@ -59,12 +63,17 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    local = local % torch.cuda.device_count()                 # (several ranks may share a GPU in the gloo smoke test)
     torch.cuda.set_device(local)
     dist = None
+    backend = os.environ.get("BVH_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only to exercise the N>1 path on one GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -98,7 +107,11 @@ def main() -> None:
             src = builder.result.d_nodes + 32 * builder.result.root + 8
             rc = lib.bvh_dev_copy(ctx.handle, root_box.data_ptr(), src, 24)
             assert rc == 0
-            dist.all_gather_into_tensor(gathered, root_box)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, root_box)
+            else:
+                host = root_box.cpu(); out = [torch.zeros(6) for _ in range(world)]
+                dist.all_gather(out, host)
 
     def barrier():
         if world > 1:
@@ -117,7 +130,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()

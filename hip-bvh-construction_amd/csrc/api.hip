@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <new>
 #include <cstring>
+#include <cstdlib>
 #include "bvh_mi355x.h"
 #include "common.hpp"
 #include "kernels.hpp"
@@ -17,15 +18,14 @@ using namespace bvh;
 namespace bvh { thread_local KernelRecorder* g_recorder = nullptr; }
 
 struct EventRecorder : KernelRecorder {
-    struct Rec { const char* name; hipEvent_t a, b; };
+    struct Rec { const char* name; hipEvent_t ev; };
     std::vector<Rec> recs; size_t used = 0;
-    void begin(hipStream_t s, const char* name) override {
-        if (used == recs.size()) { Rec r{name, nullptr, nullptr}; if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; recs.push_back(r); }
-        recs[used].name = name; (void)hipEventRecord(recs[used].a, s);
+    void mark(hipStream_t s, const char* name) override {
+        if (used == recs.size()) { Rec r{name, nullptr}; if (hipEventCreate(&r.ev) != hipSuccess) return; recs.push_back(r); }
+        recs[used].name = name; (void)hipEventRecord(recs[used].ev, s); ++used;
     }
-    void end(hipStream_t s) override { if (used < recs.size()) { (void)hipEventRecord(recs[used].b, s); ++used; } }
     void reset() { used = 0; }
-    ~EventRecorder() override { for (auto& r : recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); } }
+    ~EventRecorder() override { for (auto& r : recs) if (r.ev) (void)hipEventDestroy(r.ev); }
 };
 
 struct bvh_ctx {
@@ -57,6 +57,15 @@ struct bvh_ctx {
 };
 
 namespace {
+
+// HPLOC: asynchronous single-launch kernel below this size, level-synchronous launches above (62 small launches amortise)
+constexpr uint32_t HPLOC_LEVELS_MIN_N = 4000000;   // measured crossover on MI355X: async 3028 vs levels 2643 Mtris/s at 2 M, 3672 vs 4419 at 10 M
+inline bool use_levels(uint32_t n) {
+    const char* e = getenv("BVH_HPLOC_MODE");          // "async" / "levels" override (A/B measurements)
+    if (e && e[0] == 'a') return false;
+    if (e && e[0] == 'l') return true;
+    return n >= HPLOC_LEVELS_MIN_N;
+}
 
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return -(int)_e; } while (0)
@@ -201,9 +210,10 @@ int bvh_ctx_kernel_times(bvh_ctx* c, char* names_out, uint32_t names_cap, float*
     Bind b(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<std::string> order; std::map<std::string, std::pair<double, uint32_t>> acc;
-    for (size_t i = 0; i < c->recorder.used; ++i) {
+    for (size_t i = 0; i + 1 < c->recorder.used; ++i) {
+        if (!c->recorder.recs[i].name) continue;              // end-of-build mark
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->recorder.recs[i].a, c->recorder.recs[i].b));
+        HIP_TRY(hipEventElapsedTime(&ms, c->recorder.recs[i].ev, c->recorder.recs[i + 1].ev));
         auto it = acc.find(c->recorder.recs[i].name);
         if (it == acc.end()) { order.push_back(c->recorder.recs[i].name); acc[c->recorder.recs[i].name] = {ms, 1u}; }
         else { it->second.first += ms; it->second.second += 1; }
@@ -275,7 +285,8 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_hploc(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
+    if (use_levels(n)) launch_hploc_levels(c->stream, c->sort, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, c->small + 1);
+    else launch_hploc(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
     return herr(hipGetLastError());
 }
 
@@ -312,13 +323,15 @@ int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_
     switch (algo) {
         case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->slots, c->small); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->parent, c->flags); break;
-        case BVH_HPLOC:           launch_hploc(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
+        case BVH_HPLOC:           if (use_levels(n)) launch_hploc_levels(s, c->sort, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, c->small + 1);
+                                  else launch_hploc(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);
                                   r = run_ploc(c, n, c->nodes, c->leaves, c->ploc, &ploc_iters); if (r) return r;
                                   out->d_leaves = c->leaves; out->layout = 1; break;
     }
     HIP_TRY(hipGetLastError());
+    if (c->kernel_profiling) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
         HIP_TRY(hipMemcpyAsync(&out->root, c->small, 4, hipMemcpyDeviceToHost, s));

@@ -69,6 +69,130 @@ __device__ __forceinline__ float push_f32(int dst, float v) { return __int_as_fl
 // cidx entry: {cluster id, rep}
 __device__ __forceinline__ u64 entry(u32 id, u32 rep) { return (u64)id | ((u64)rep << 32); }
 
+// ---- one merge pass: every 32-lane half with `have` runs the plocMerge (:220-255) of the LBVH node at gap tP with leaf
+// range [tL, tR].  AGENT = true: survivors / node boxes may have been written by other workgroups of the same launch
+// (agent-scope loads and write-through stores); AGENT = false: everything read was written by earlier launches.
+template <bool AGENT> __device__ __forceinline__ u64 ld_e(const u64* p) { return AGENT ? ld_agent(p) : *p; }
+template <bool AGENT> __device__ __forceinline__ u32 ld_w(const u32* p) { return AGENT ? ld_agent(p) : *p; }
+template <bool AGENT> __device__ __forceinline__ void st_e(u64* p, u64 v) { if (AGENT) st_agent(p, v); else *p = v; }
+template <bool AGENT> __device__ __forceinline__ void st_w(u32* p, u32 v) { if (AGENT) st_agent(p, v); else *p = v; }
+template <bool AGENT> __device__ __forceinline__ Box node_box(const bvh2_node* n) {
+    if (AGENT) return node_box_agent(n);
+    const float* f = reinterpret_cast<const float*>(n) + 2;
+    return { f[0], f[1], f[2], f[3], f[4], f[5] };
+}
+template <bool AGENT> __device__ __forceinline__ void node_store(bvh2_node* n, u32 l, u32 r, const Box& b) {
+    if (AGENT) { node_store_agent(n, l, r, b); return; }
+    float4* q = reinterpret_cast<float4*>(n);
+    q[0] = make_float4(__uint_as_float(l), __uint_as_float(r), b.lx, b.ly);
+    q[1] = make_float4(b.lz, b.hx, b.hy, b.hz);
+}
+
+struct HpEntry { u32 id, rep, prim; };   // prim: primitive index prefetched for implicit leaves, INV otherwise
+
+// loadIndices (:192-206): slots 0..15 <- left child, 16..31 <- right child; small children are implicit leaves
+template <bool AGENT>
+__device__ __forceinline__ HpEntry load_entry(bool have, u32 tL, u32 tR, u32 tP, const u32* __restrict__ svals, const u64* cidx, u32 ni, int slot) {
+        const bool is_left = slot < 16;
+        const u32 s = (u32)(slot & 15);
+        const u32 c_start = is_left ? tL : tP + 1, c_len = is_left ? (tP - tL + 1) : (tR - tP);
+        HpEntry en = { INV, INV, INV };
+        if (have) {
+            if (c_len > HP_HALF) { const u64 e = ld_e<AGENT>(cidx + c_start + s); en.id = (u32)e; en.rep = (u32)(e >> 32); }
+            else if (s < c_len) { en.rep = c_start + s; en.id = ni + en.rep; en.prim = svals[en.rep]; }
+        }
+        return en;
+}
+
+template <bool AGENT>
+__device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
+                                           const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
+                                           u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
+        const bool final_ = have && tL == 0 && tR == ni;
+        u32 id = en.id, rep = en.rep, prim = en.prim;
+        const u32 vb = (u32)(__ballot(id != INV) >> hbase);
+        const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
+        u32 cnt = nl + nr;
+        {   // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
+            const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
+            const u32 ti = (u32)__shfl((int)id, src), tr = (u32)__shfl((int)rep, src), tp = (u32)__shfl((int)prim, src);
+            id = ((u32)slot < cnt) ? ti : INV; rep = tr; prim = tp;
+        }
+        Box b = box_empty();
+        if (id != INV) {
+            if (id >= ni) {   // first (and only) load of this leaf: fused SetupClusters (:44-47)
+                if (prim == INV) prim = svals[rep];
+                b = box_load(boxes + prim);
+                float* f = reinterpret_cast<float*>(leaves + rep);
+                reinterpret_cast<u32*>(f)[0] = prim;
+                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+            } else b = node_box<AGENT>(nodes + id);                                                  // :242-246
+        }
+        const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
+        while (__ballot(have && cnt > threshold)) {
+            const bool act = have && cnt > threshold;
+            // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
+            // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
+            // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
+            u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
+            Box nb = b;
+#pragma unroll
+            for (int r = 1; r <= HP_RADIUS; ++r) {
+                nb = box_shl1(nb);                                               // box of slot + r
+                const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
+                const u32 ab_left = (u32)__shfl_up((int)ab, r);                  // area(slot - r, slot)
+                if ((u32)(slot + r) < cnt && ab < abR) { abR = ab; idR = slot + r; }
+                if (slot >= r && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - r; }
+            }
+            // mergeClusters (:126-190)
+            const int nbr = (abL <= abR) ? idL : idR;
+            const int nsrc = hbase + nbr;
+            const u32 nbr_of_nbr = (u32)__shfl(nbr, nsrc);
+            const bool in = act && (u32)slot < cnt;
+            const bool mutual = in && nbr_of_nbr == (u32)slot;
+            const bool merge = mutual && slot < nbr;
+            const bool absorbed = mutual && slot > nbr;
+            const u32 id_nb = (u32)__shfl((int)id, nsrc);
+            const u32 rep_nb = (u32)__shfl((int)rep, nsrc);
+            const Box bn = shfl_box(b, nsrc);
+            if (merge) {
+                b = box_union(b, bn);
+                u32 at = rep_nb - 1u;                            // the absorbed partner's rep is retired here, once
+                u32 l = id, r = id_nb;
+                if (final_ && cnt == 2u && at != 0u) {
+                    // the root must be node 0 (:165-167 makes the last allocation 0): move node 0's occupant to the root's
+                    // natural slot and re-point its parent
+                    const u64* q0 = reinterpret_cast<const u64*>(nodes);
+                    u64* qs = reinterpret_cast<u64*>(nodes + at);
+                    const u64 w0 = ld_e<AGENT>(q0 + 0), w1 = ld_e<AGENT>(q0 + 1), w2 = ld_e<AGENT>(q0 + 2), w3 = ld_e<AGENT>(q0 + 3);
+                    st_e<AGENT>(qs + 0, w0); st_e<AGENT>(qs + 1, w1); st_e<AGENT>(qs + 2, w2); st_e<AGENT>(qs + 3, w3);
+                    if (l == 0u) l = at;
+                    else if (r == 0u) r = at;
+                    else {
+                        const u32 pw = ld_w<AGENT>(zero_parent);
+                        st_w<AGENT>(reinterpret_cast<u32*>(nodes + (pw >> 1)) + (pw & 1u), at);
+                    }
+                    at = 0u;
+                } else if (l == 0u || r == 0u) st_w<AGENT>(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
+                node_store<AGENT>(nodes + at, l, r, b);
+                id = at;
+            }
+            // compaction: survivors and merged clusters keep their order (:176-187 as "valid slots write to their rank").
+            // Slot 31 of a half is never a destination after a round (>= 1 merge), so it serves as the sink.
+            const bool keep = in && !absorbed;
+            const u32 kh = (u32)(__ballot(keep) >> hbase);
+            const u32 newcnt = (u32)__popc(kh);
+            const int dst = act ? (hbase + (keep ? (int)__popc(kh & ((1u << slot) - 1u)) : 31)) : lane;
+            id = push_u32(dst, id); rep = push_u32(dst, rep);
+            b.lx = push_f32(dst, b.lx); b.ly = push_f32(dst, b.ly); b.lz = push_f32(dst, b.lz);
+            b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
+            if (act) { if ((u32)slot >= newcnt) id = INV; cnt = newcnt; }
+        }
+        // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
+        if (have && !final_ && slot < 16) st_e<AGENT>(cidx + tL + slot, entry(id, rep));
+
+}
+
 #ifndef HP_WAVES
 #define HP_WAVES 1
 #endif
@@ -138,97 +262,7 @@ __global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __
         const bool have = own >= 0;
         const int osrc = have ? own : 0;
         const u32 tL = (u32)__shfl((int)L, osrc), tR = (u32)__shfl((int)R, osrc), tP = (u32)__shfl((int)pc, osrc);
-        const bool final_ = have && tL == 0 && tR == ni;
-
-        // -- loadIndices (:192-206): slots 0..15 <- left child, 16..31 <- right child; small children are implicit leaves
-        const bool is_left = slot < 16;
-        const u32 s = (u32)(slot & 15);
-        const u32 c_start = is_left ? tL : tP + 1, c_len = is_left ? (tP - tL + 1) : (tR - tP);
-        u32 id = INV, rep = INV;
-        if (have) {
-            if (c_len > HP_HALF) { const u64 e = ld_agent(cidx + c_start + s); id = (u32)e; rep = (u32)(e >> 32); }
-            else if (s < c_len) { rep = c_start + s; id = ni + rep; }
-        }
-        const u32 vb = (u32)(__ballot(id != INV) >> hbase);
-        const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
-        u32 cnt = nl + nr;
-        {   // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
-            const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
-            const u32 ti = (u32)__shfl((int)id, src), tr = (u32)__shfl((int)rep, src);
-            id = ((u32)slot < cnt) ? ti : INV; rep = tr;
-        }
-        Box b = box_empty();
-        if (id != INV) {
-            if (id >= ni) {   // first (and only) load of this leaf: fused SetupClusters (:44-47)
-                const u32 prim = svals[rep];
-                b = box_load(boxes + prim);
-                float* f = reinterpret_cast<float*>(leaves + rep);
-                reinterpret_cast<u32*>(f)[0] = prim;
-                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-            } else b = node_box_agent(nodes + id);                                                  // :242-246
-        }
-        const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
-        while (__ballot(have && cnt > threshold)) {
-            const bool act = have && cnt > threshold;
-            // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
-            // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
-            // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
-            u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
-            Box nb = b;
-#pragma unroll
-            for (int r = 1; r <= HP_RADIUS; ++r) {
-                nb = box_shl1(nb);                                               // box of slot + r
-                const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
-                const u32 ab_left = (u32)__shfl_up((int)ab, r);                  // area(slot - r, slot)
-                if ((u32)(slot + r) < cnt && ab < abR) { abR = ab; idR = slot + r; }
-                if (slot >= r && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - r; }
-            }
-            // mergeClusters (:126-190)
-            const int nbr = (abL <= abR) ? idL : idR;
-            const int nsrc = hbase + nbr;
-            const u32 nbr_of_nbr = (u32)__shfl(nbr, nsrc);
-            const bool in = act && (u32)slot < cnt;
-            const bool mutual = in && nbr_of_nbr == (u32)slot;
-            const bool merge = mutual && slot < nbr;
-            const bool absorbed = mutual && slot > nbr;
-            const u32 id_nb = (u32)__shfl((int)id, nsrc);
-            const u32 rep_nb = (u32)__shfl((int)rep, nsrc);
-            const Box bn = shfl_box(b, nsrc);
-            if (merge) {
-                b = box_union(b, bn);
-                u32 at = rep_nb - 1u;                            // the absorbed partner's rep is retired here, once
-                u32 l = id, r = id_nb;
-                if (final_ && cnt == 2u && at != 0u) {
-                    // the root must be node 0 (:165-167 makes the last allocation 0): move node 0's occupant to the root's
-                    // natural slot and re-point its parent
-                    const u64* q0 = reinterpret_cast<const u64*>(nodes);
-                    u64* qs = reinterpret_cast<u64*>(nodes + at);
-                    const u64 w0 = ld_agent(q0 + 0), w1 = ld_agent(q0 + 1), w2 = ld_agent(q0 + 2), w3 = ld_agent(q0 + 3);
-                    st_agent(qs + 0, w0); st_agent(qs + 1, w1); st_agent(qs + 2, w2); st_agent(qs + 3, w3);
-                    if (l == 0u) l = at;
-                    else if (r == 0u) r = at;
-                    else {
-                        const u32 pw = ld_agent(zero_parent);
-                        st_agent(reinterpret_cast<u32*>(nodes + (pw >> 1)) + (pw & 1u), at);
-                    }
-                    at = 0u;
-                } else if (l == 0u || r == 0u) st_agent(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
-                node_store_agent(nodes + at, l, r, b);
-                id = at;
-            }
-            // compaction: survivors and merged clusters keep their order (:176-187 as "valid slots write to their rank").
-            // Slot 31 of a half is never a destination after a round (>= 1 merge), so it serves as the sink.
-            const bool keep = in && !absorbed;
-            const u32 kh = (u32)(__ballot(keep) >> hbase);
-            const u32 newcnt = (u32)__popc(kh);
-            const int dst = act ? (hbase + (keep ? (int)__popc(kh & ((1u << slot) - 1u)) : 31)) : lane;
-            id = push_u32(dst, id); rep = push_u32(dst, rep);
-            b.lx = push_f32(dst, b.lx); b.ly = push_f32(dst, b.ly); b.lz = push_f32(dst, b.lz);
-            b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
-            if (act) { if ((u32)slot >= newcnt) id = INV; cnt = newcnt; }
-        }
-        // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
-        if (have && !final_ && slot < 16) st_agent(cidx + tL + slot, entry(id, rep));
+        merge_exec<true>(have, tL, tR, load_entry<true>(have, tL, tR, tP, svals, cidx, ni, slot), boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
 
         // -- the owners hand their finished range to the parent node
         if (ready && (lane == ownA || lane == ownB)) {
@@ -251,6 +285,77 @@ __global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __
     }
 }
 
+// =====================================================================================================================
+// Level-synchronous variant for large inputs.
+//
+// In the LBVH hierarchy a parent's common prefix is strictly shorter than its children's, so "process nodes by decreasing
+// prefix length c0" is a topological order that needs no dependency tracking at all: k_hp_plan computes every node's range
+// and c0 from the keys, the one-sweep sort (one 8-bit pass) groups the big nodes by level 63 - c0, and one launch per level
+// runs that level's merge tasks — two per wave64, always paired, with plain (cached) loads and stores, no atomics, no
+// drains: the kernel boundary is the hand-off.  Empty levels cost one ~2 us launch each.
+// =====================================================================================================================
+constexpr u32 HP_NO_TASK = 0xFFu;
+
+__global__ __launch_bounds__(HP_BLOCK) void k_hp_plan(const u32* __restrict__ skeys, u64* __restrict__ ranges,
+                                                      u32* __restrict__ level_keys, u32 n) {
+    __shared__ u32 s_keys[HP_BLOCK * 3 + 1];
+    const u32 ni = n - 1;
+    const u32 pc = blockIdx.x * HP_BLOCK + threadIdx.x;
+    const int g0 = (int)(blockIdx.x * HP_BLOCK);
+    const int w0 = g0 - HP_BLOCK;
+    for (int k = threadIdx.x; k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : 0u; }
+    __syncthreads();
+    if (pc >= ni) return;
+    auto key_at = [&](int j) -> u64 {
+        const u32 k = ((u32)(j - w0) <= (u32)(HP_BLOCK * 3)) ? s_keys[j - w0] : skeys[j];
+        return ((u64)k << 32) | (u32)j;
+    };
+    const int p = (int)pc;
+    const u64 kp = key_at(p);
+    const int c0 = clz64(kp ^ key_at(p + 1));
+    auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(key_at(j) ^ kp) >= c0; };
+    int step = 1;
+    while (inside(p - step)) step <<= 1;
+    int lo = p - (step >> 1);
+    for (int t = step >> 2; t > 0; t >>= 1) if (inside(lo - t)) lo -= t;
+    step = 1;
+    while (inside(p + 1 + step)) step <<= 1;
+    int hi = p + 1 + (step >> 1);
+    for (int t = step >> 2; t > 0; t >>= 1) if (inside(hi + t)) hi += t;
+    const u32 size = (u32)(hi - lo + 1);
+    const bool big = size > HP_HALF || size == n;
+    level_keys[pc] = big ? (u32)(63 - c0) : HP_NO_TASK;
+    if (big) ranges[pc] = (u64)(u32)lo | ((u64)(u32)hi << 32);
+}
+
+// level_offsets: the sort's exclusive digit offsets (hist after k_scan_hist): tasks of level v are task_ids[off[v] .. off[v+1])
+__global__ __launch_bounds__(HP_BLOCK) void k_hp_level(const u32* __restrict__ level_offsets, int level, const u32* __restrict__ task_ids,
+                                                       const u64* __restrict__ ranges, const bvh_aabb* __restrict__ boxes,
+                                                       const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
+                                                       u64* cidx, u32* zero_parent, u32 n) {
+    const u32 base = level_offsets[level], count = level_offsets[level + 1] - base;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
+    const u32 ni = n - 1;
+    const u32 stride = gridDim.x * (HP_BLOCK / 32);
+    const u32 t0 = blockIdx.x * (HP_BLOCK / 32) + (threadIdx.x >> 6) * 2;          // wave-uniform first task of the wave
+    // Software pipeline over the wave's tasks: task id three iterations ahead, its range two ahead, its cluster entries
+    // (survivor ids or the leaves' primitive indices) one ahead — so an iteration's own critical path is one gather
+    // (boxes) + the merge rounds; the dependent id -> range -> entry loads of later tasks are in flight meanwhile.
+    auto task_at = [&](u32 k) -> u32 { const u32 t = t0 + k * stride + (u32)half; return t < count ? task_ids[base + t] : INV; };
+    auto range_of = [&](u32 p) -> u64 { return p != INV ? ranges[p] : 0ull; };
+    u32 p0 = task_at(0), p1 = task_at(1), p2 = task_at(2);
+    u64 r0 = range_of(p0), r1 = range_of(p1);
+    HpEntry e0 = load_entry<false>(p0 != INV, (u32)r0, (u32)(r0 >> 32), p0, svals, cidx, ni, slot);
+    for (u32 k = 0; t0 + k * stride < count; ++k) {
+        const u32 p3 = task_at(k + 3);
+        const u64 r2 = range_of(p2);
+        const HpEntry e1 = load_entry<false>(p1 != INV, (u32)r1, (u32)(r1 >> 32), p1, svals, cidx, ni, slot);
+        merge_exec<false>(p0 != INV, (u32)r0, (u32)(r0 >> 32), e0, boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
+        p0 = p1; r0 = r1; e0 = e1; p1 = p2; r1 = r2; p2 = p3;
+    }
+}
+
 void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,
                            uint32_t* d_cluster_idx, uint32_t* d_parent) {
     { KernelScope ks(s, "k_setup_clusters"); hipLaunchKernelGGL(k_setup_clusters, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_svals,
@@ -263,6 +368,24 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, c
     const u32 gaps = n - 1;
     { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, n, getenv("BVH_HPLOC_DEBUG") ? atoi(getenv("BVH_HPLOC_DEBUG")) : 0); }
+}
+
+// Level-synchronous HPLOC for large n.  level_keys / task_keys / task_ids: u32[n] scratch; sc: the sort's scratch (re-armed here).
+void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                         void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
+                         uint32_t* d_task_keys, uint32_t* d_task_ids, uint32_t* d_zero_parent) {
+    const u32 gaps = n - 1;
+    { KernelScope ks(s, "k_hp_plan"); hipLaunchKernelGGL(k_hp_plan, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, d_skeys, d_ranges, d_level_keys, n); }
+    sort_prepare(s, sc, gaps);
+    sort_pairs(s, sc, d_level_keys, nullptr, gaps, d_task_keys, d_task_ids, 0, 8, false);     // one pass; sc.hist = level offsets
+    const u32 max_tasks = gaps / 17 + 1;
+    u32 grid = (max_tasks + (HP_BLOCK / 32) - 1) / (HP_BLOCK / 32);
+    if (grid > 2048u) grid = 2048u;
+    KernelScope ks(s, "k_hp_level");                  // all 62 launches are timed as one group
+    for (int level = 0; level < 62; ++level) {       // level = 63 - c0, c0 in [2, 63]
+        hipLaunchKernelGGL(k_hp_level, dim3(grid), dim3(HP_BLOCK), 0, s, (const u32*)sc.hist, level, (const u32*)d_task_ids, (const u64*)d_ranges,
+                           (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_zero_parent, n);
+    }
 }
 
 } // namespace bvh

@@ -5,18 +5,17 @@
 
 namespace bvh {
 
-// Optional per-kernel timing (bvh_ctx_set_profiling(ctx, 2)): launchers wrap each kernel launch in a KernelScope; when a
-// recorder is installed for the calling thread it brackets the launch with two hipEvents on the launch stream.
+// Optional per-kernel timing (bvh_ctx_set_profiling(ctx, 2)): launchers announce each kernel (or group of launches of one
+// kernel) with a KernelScope; when a recorder is installed for the calling thread it records ONE hipEvent on the launch
+// stream at that point.  The time between two consecutive marks is attributed to the earlier mark's name (kernel duration
+// including its launch boundary) — half the events of a begin/end pair, which matters when a build is ~70 launches.
 struct KernelRecorder {
-    virtual void begin(hipStream_t s, const char* name) = 0;
-    virtual void end(hipStream_t s) = 0;
+    virtual void mark(hipStream_t s, const char* name) = 0;
     virtual ~KernelRecorder() {}
 };
 extern thread_local KernelRecorder* g_recorder;
 struct KernelScope {
-    hipStream_t s; bool on;
-    KernelScope(hipStream_t stream, const char* name) : s(stream), on(g_recorder != nullptr) { if (on) g_recorder->begin(s, name); }
-    ~KernelScope() { if (on) g_recorder->end(s); }
+    KernelScope(hipStream_t stream, const char* name) { if (g_recorder) g_recorder->mark(stream, name); }
 };
 
 constexpr int EM_BLOCK = 256;
@@ -57,6 +56,9 @@ void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx /*u64[n] {id,rep}*/, uint64_t* d_ranges /*u64[n]*/,
                   uint32_t* d_counter /*u32[n]*/, uint32_t* d_zero_parent /*u32[1]*/);
+void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                         void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
+                         uint32_t* d_task_keys, uint32_t* d_task_ids, uint32_t* d_zero_parent);
 struct PlocScratch {
     uint32_t* ids0;          // u32[n]
     uint32_t* ids1;          // u32[n]

@@ -218,9 +218,9 @@ void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_node
     const u32 chunks = ploc_chunks(n);
     const u32 grid = chunks < 1024u ? chunks : 1024u;
     u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
+    KernelScope ks(s, "k_ploc_iter");                   // the batch of launches is timed as one group
     for (int k = first; k < first + count; ++k) {
         const bool even = ((k + parity) & 1) == 0;
-        KernelScope ks(s, "k_ploc_iter");
         hipLaunchKernelGGL(k_ploc_iter, dim3(grid), dim3(PL_BLOCK), 0, s, even ? sc.ids0 : sc.ids1, even ? sc.ids1 : sc.ids0,
                            (bvh2_node*)d_nodes, (const bvh_primref*)d_leaves, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
     }

@@ -209,6 +209,7 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
     const u32 tiles = sort_tiles(n);
     if (!hist_ready) {
         const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
+        KernelScope ks(s, "k_hist");
         hipLaunchKernelGGL(k_hist, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
     { KernelScope ks(s, "k_scan_hist"); hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist); }
