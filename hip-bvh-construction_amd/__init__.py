@@ -26,6 +26,9 @@ LIB_PATH = os.environ.get("BVH_MI355X_LIB", os.path.join(_HERE, "libbvh_mi355x.s
 AABB = np.dtype([("min", "<f4", 3), ("max", "<f4", 3)])
 BVH2_NODE = np.dtype([("left", "<u4"), ("right", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
 PRIMREF = np.dtype([("prim", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
+BVH4_NODE = np.dtype([("aabb", AABB, 4), ("child", "<u4", 4), ("parent", "<u4"), ("count", "<u4"), ("pad", "<u4", 2)])
+PRIM_NODE = np.dtype([("prim", "<u4"), ("parent", "<u4")])
+assert BVH4_NODE.itemsize == 128 and PRIM_NODE.itemsize == 8
 assert AABB.itemsize == 24 and BVH2_NODE.itemsize == 32 and PRIMREF.itemsize == 28
 INVALID = 0xFFFFFFFF
 
@@ -36,7 +39,7 @@ ALGO_NAMES = {0: "TwoPassLbvh", 1: "SinglePassLbvh", 2: "PLOCNew", 3: "HPLOC"}
 EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
-    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_sah_cost",
+    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_sah_cost",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_version",
 ]
 
@@ -98,6 +101,7 @@ def lib() -> C.CDLL:
         "bvh_dev_alloc": ([vp, u64, C.POINTER(vp)], i32), "bvh_dev_free": ([vp, vp], i32),
         "bvh_dev_upload": ([vp, vp, vp, u64], i32), "bvh_dev_download": ([vp, vp, vp, u64], i32),
         "bvh_dev_copy": ([vp, vp, vp, u64], i32),
+        "bvh_collapse4": ([vp, C.POINTER(Result), vp, vp, C.POINTER(u32)], i32),
         "bvh_ctx_kernel_times": ([vp, C.c_char_p, u32, C.POINTER(C.c_float), C.POINTER(u32), u32], i32),
         "bvh_version": ([], C.c_char_p),
     }
@@ -263,6 +267,16 @@ class _Builder:
         _check(lib().bvh_sah_cost(self._ctx.handle, C.byref(self.result), C.byref(c)), "bvh_sah_cost")
         self.m_cost = c.value
         return c.value
+
+    def collapse4(self):
+        """BVH2 -> BVH4 (CollapseToWide4Bvh): returns (Bvh4Node[n_wide], PrimNode[n], n_wide) as numpy arrays"""
+        n = self.result.n_leaves
+        wide = self._ctx.alloc(n * BVH4_NODE.itemsize); prims = self._ctx.alloc(n * PRIM_NODE.itemsize)
+        nw = C.c_uint32()
+        _check(lib().bvh_collapse4(self._ctx.handle, C.byref(self.result), wide.ptr, prims.ptr, C.byref(nw)), "bvh_collapse4")
+        out = wide.download(BVH4_NODE, nw.value), prims.download(PRIM_NODE, n), int(nw.value)
+        wide.free(); prims.free()
+        return out
 
     def to_lbvh_layout(self) -> np.ndarray:
         n = self.result.n_leaves

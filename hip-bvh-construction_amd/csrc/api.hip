@@ -364,6 +364,32 @@ int bvh_to_lbvh_layout(bvh_ctx* c, const bvh_result* in, void* d_out) {
     return herr(hipGetLastError());
 }
 
+// CollapseToWide4Bvh + its host set-up (src/TwoPassLbvh.cpp:154-183).  d_bvh4: Bvh4Node[n] (128 B), d_primnodes: PrimNode[n].
+int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primnodes, uint32_t* n_wide_out) {
+    if (!c || !in || !in->d_nodes || !d_bvh4 || !d_primnodes) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    const uint32_t n = in->n_leaves;
+    int r = ensure_capacity(c, n); if (r) return r;
+    hipStream_t s = c->stream;
+    uint2* taskq = reinterpret_cast<uint2*>(c->slots);                 // u64[n] scratch, free after a build
+    u32* state = c->ploc.state;                                         // >= COLLAPSE_STATE_WORDS words
+    static_assert(PLOC_STATE_WORDS >= COLLAPSE_STATE_WORDS, "state scratch");
+    collapse_begin(s, taskq, state, in->root);
+    u32 host[COLLAPSE_STATE_WORDS];
+    int first = 0;
+    while (first < COLLAPSE_MAX_LEVELS) {
+        const int count = (COLLAPSE_MAX_LEVELS - first) < 48 ? (COLLAPSE_MAX_LEVELS - first) : 48;
+        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, first, count, n, (int)in->layout);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host, state, sizeof host, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        first += count;
+        // done when the last processed level created nothing: allocation counter == start of the next level's snapshot
+        if (host[0] == host[1 + first]) { if (n_wide_out) *n_wide_out = host[0]; return 0; }
+    }
+    return BVH_E_INTERNAL;
+}
+
 int bvh_sah_cost(bvh_ctx* c, const bvh_result* in, double* cost_out) {
     if (!c || !in || !cost_out || !in->d_nodes) return BVH_E_INVALID_ARG;
     Bind b(c->device);

@@ -75,6 +75,13 @@ void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count);
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity);
 
+// ---- BVH2 -> BVH4 collapse (collapse.hip)
+constexpr int COLLAPSE_MAX_LEVELS = 192;
+constexpr int COLLAPSE_STATE_WORDS = COLLAPSE_MAX_LEVELS + 4;
+void collapse_begin(hipStream_t s, uint2* d_taskq, uint32_t* d_state, uint32_t root);
+void collapse_enqueue(hipStream_t s, const void* d_nodes, const void* d_leaves, void* d_wide, void* d_prims, uint2* d_taskq,
+                      uint32_t* d_state, int first, int count, uint32_t n, int layout);
+
 // ---- helpers (misc.hip)
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out);
 void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t root, uint32_t n, int layout, double* d_out /*[1], zeroed inside*/);

@@ -117,6 +117,10 @@ int  bvh_emit_hploc(bvh_ctx* ctx, const void* d_prim_aabbs, const uint32_t* d_so
 /* PLOC layout -> LBVH layout (Bvh2Node[2n-1]) so that the reference's traversal kernels (src/TraversalKernel.h) can
  * consume PLOC/HPLOC trees; the adapter the reference never wrote. */
 int  bvh_to_lbvh_layout(bvh_ctx* ctx, const bvh_result* in, void* d_nodes_2n_minus_1);
+/* CollapseToWide4Bvh (src/TwoPassLbvhKernel.h:237-336, src/Ploc++Kernel.h:364-465) + host set-up (src/TwoPassLbvh.cpp:154-183):
+ * BVH2 -> BVH4.  d_bvh4: Bvh4Node[n] (128 B each, src/Common.h:560-566), d_primnodes: PrimNode[n] (src/Common.h:568-572);
+ * wide root = node 0; *n_wide_out = number of wide nodes.  Blocking (reads the level bounds back). */
+int  bvh_collapse4(bvh_ctx* ctx, const bvh_result* in, void* d_bvh4, void* d_primnodes, uint32_t* n_wide_out);
 /* BVH2 SAH cost with the formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349), device reduction, f64. */
 int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
 /* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL */

@@ -741,6 +741,39 @@ u32 orc_collapse4(const void* nodes, const void* leaves, u32 root, u32 n, int la
     return next;
 }
 
+// canonical (numbering independent, child-slot order significant) hash of a BVH4; also checks structure:
+// returns 0 if a wide node is visited twice, a child index is out of range, or a PrimNode's parent link is wrong
+u64 orc_topology_hash4(const void* bvh4, const void* prim_nodes, u32 total, u32 n) {
+    const Node4* w = (const Node4*)bvh4; const PrimNode* pn = (const PrimNode*)prim_nodes;
+    const u32 ni = n - 1;
+    std::vector<u64> h(total, 0); std::vector<uint8_t> state(total, 0);
+    std::vector<u32> stack; stack.push_back(0);
+    while (!stack.empty()) {
+        const u32 c = stack.back();
+        if (c >= total) return 0;
+        if (state[c] == 0) {
+            state[c] = 1;
+            if (w[c].count < 2 || w[c].count > 4) return 0;
+            for (u32 k = 0; k < w[c].count; ++k) {
+                const u32 ch = w[c].child[k];
+                if (ch < ni) { if (ch >= total || state[ch] != 0 || w[ch].parent != c) return 0; stack.push_back(ch); }
+                else if (ch - ni >= n || pn[ch - ni].parent != c) return 0;
+            }
+        } else {
+            if (state[c] == 1) {
+                u64 acc = 0x243f6a8885a308d3ull + w[c].count;
+                for (u32 k = 0; k < w[c].count; ++k) {
+                    const u32 ch = w[c].child[k];
+                    acc = hnode(acc, ch < ni ? h[ch] : hleaf(pn[ch - ni].prim));
+                }
+                h[c] = acc; state[c] = 2;
+            }
+            stack.pop_back();
+        }
+    }
+    return h[0];
+}
+
 // Utility::calculatebvh4Cost, src/Utility.cpp:351-396 (f32, node-index order) + f64 twin
 double orc_sah_bvh4(const void* bvh4, const void* prim_nodes, const void* prim_boxes, u32 total, u32 n, float* f32_out) {
     const Node4* w = (const Node4*)bvh4; const PrimNode* pn = (const PrimNode*)prim_nodes; const Box* pb = (const Box*)prim_boxes;

@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
         L.orc_binned_sah_build.argtypes = [vp, u32, vp]; L.orc_binned_sah_build.restype = u32
         L.orc_sah_binned.argtypes = [vp, u32, u32, C.POINTER(C.c_float)]; L.orc_sah_binned.restype = C.c_double
         L.orc_collapse4.argtypes = [vp, vp, u32, u32, C.c_int, vp, vp]; L.orc_collapse4.restype = u32
+        L.orc_topology_hash4.argtypes = [vp, vp, u32, u32]; L.orc_topology_hash4.restype = u64
         L.orc_sah_bvh4.argtypes = [vp, vp, vp, u32, u32, C.POINTER(C.c_float)]; L.orc_sah_bvh4.restype = C.c_double
         _lib = L
     return _lib
@@ -205,6 +206,10 @@ def collapse4(nodes, leaves, root, n, layout):
     w = np.zeros(n, dtype=BVH4_NODE); pn = np.zeros(n, dtype=PRIM_NODE)
     total = lib().orc_collapse4(nodes.ctypes.data, _p(leaves), root, n, layout, w.ctypes.data, pn.ctypes.data)
     return w, pn, int(total)
+
+
+def topology_hash4(w, pn, total, n) -> int:
+    return int(lib().orc_topology_hash4(np.ascontiguousarray(w).ctypes.data, np.ascontiguousarray(pn).ctypes.data, total, n))
 
 
 def sah_bvh4(w, pn, prim_boxes, total, n):

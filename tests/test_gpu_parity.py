@@ -137,3 +137,30 @@ def test_repeat_builds_same_ctx(pkg, orc, ctx, cases):
         b = pkg.BUILDERS[algo]().build(ctx, tris); got = b.download(); ref = orc.build_tree(algo, tris)
         assert orc.topology_hash(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == \
                orc.topology_hash(ref["nodes"], ref["leaves"], ref["root"], n, ref["layout"])
+
+
+@pytest.mark.parametrize("name", ["uniform_2", "uniform_3", "uniform_33", "uniform_1000", "uniform_50k", "sponza_262k", "dups_3000"])
+@pytest.mark.parametrize("algo", [1, 2, 3])
+def test_collapse4(pkg, orc, ctx, cases, name, algo):
+    """BVH2 -> BVH4 collapse (config 4's n-wide collapse): same wide topology and BVH4 SAH as the oracle's restatement of
+    CollapseToWide4Bvh applied to the same BVH2; the reference's own validator / cost function accept it."""
+    tris = cases[name]; n = len(tris)
+    b = pkg.BUILDERS[algo]().build(ctx, tris)
+    got = b.download()
+    wide, prims, total = b.collapse4()
+    ow, opn, ototal = orc.collapse4(got["nodes"], got["leaves"], got["root"], n, got["layout"])
+    assert total == ototal
+    hsh = orc.topology_hash4(wide, prims, total, n)
+    assert hsh != 0 and hsh == orc.topology_hash4(ow, opn, ototal, n)
+    assert np.array_equal(np.sort(prims["prim"]), np.arange(n, dtype=np.uint32))
+    boxes, _ = orc.prim_bounds(tris)
+    c_got = orc.sah_bvh4(wide, prims, boxes, total, n)[0]; c_orc = orc.sah_bvh4(ow, opn, boxes, ototal, n)[0]
+    assert abs(c_got - c_orc) <= 1e-9 * c_orc
+    R = orc.ref_utility()
+    if R is not None:
+        w = np.ascontiguousarray(wide); p = np.ascontiguousarray(prims)
+        depth_ok = n <= 60_000                      # the reference validator's DFS stack is 64 entries
+        if depth_ok:
+            assert R.ref_checkLBvh4Correctness(w.ctypes.data, p.ctypes.data, 0, n - 1) == 1
+        # f32 accumulation in node-index order, exactly as the reference does it (the f64 value differs by accumulated rounding)
+        assert R.ref_calculatebvh4Cost(w.ctypes.data, p.ctypes.data, boxes.ctypes.data, 0, total, n - 1) == pytest.approx(orc.sah_bvh4(wide, prims, boxes, total, n)[1], rel=1e-6)
