@@ -28,6 +28,27 @@ BVH2_NODE = np.dtype([("left", "<u4"), ("right", "<u4"), ("min", "<f4", 3), ("ma
 PRIMREF = np.dtype([("prim", "<u4"), ("min", "<f4", 3), ("max", "<f4", 3)])
 BVH4_NODE = np.dtype([("aabb", AABB, 4), ("child", "<u4", 4), ("parent", "<u4"), ("count", "<u4"), ("pad", "<u4", 2)])
 PRIM_NODE = np.dtype([("prim", "<u4"), ("parent", "<u4")])
+RAY = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("tmin", "<f4"), ("tmax", "<f4")])
+CAMERA = np.dtype([("eye", "<f4", 4), ("quat", "<f4", 4), ("fov", "<f4"), ("near", "<f4"), ("far", "<f4"), ("pad", "<f4"), ("pad2", "<f4", 4)])
+TRANSFORMATION = np.dtype([("translation", "<f4", 3), ("pad", "<f4"), ("scale", "<f4", 3), ("pad1", "<f4"), ("quat", "<f4", 4), ("pad2", "<f4", 4)])
+assert RAY.itemsize == 32 and CAMERA.itemsize == 64 and TRANSFORMATION.itemsize == 64
+
+
+def qt_rotation(axis_angle):
+    """qtRotation (src/Common.h:461-472) in float32"""
+    ax = np.asarray(axis_angle[:3], dtype=np.float32); ang = np.float32(axis_angle[3])
+    ax = ax / np.sqrt(np.float32(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), dtype=np.float32)
+    s = np.float32(np.sin(ang / np.float32(2.0), dtype=np.float32)); c = np.float32(np.cos(ang / np.float32(2.0), dtype=np.float32))
+    return np.array([ax[0] * s, ax[1] * s, ax[2] * s, c], dtype=np.float32)
+
+
+def cornell_view():
+    """camera + transformation of the reference's traverseBvh (src/TwoPassLbvh.cpp:202-215)"""
+    cam = np.zeros(1, dtype=CAMERA); xf = np.zeros(1, dtype=TRANSFORMATION)
+    cam["eye"][0] = (0.0, 2.5, 5.8, 0.0); cam["quat"][0] = qt_rotation((0.0, 0.0, 1.0, -1.57))
+    cam["fov"][0] = np.float32(45.0) * np.float32(3.14159265358979323846) / np.float32(180.0); cam["near"][0] = 0.0; cam["far"][0] = 100000.0
+    xf["translation"][0] = (0.0, 0.0, -5.0); xf["scale"][0] = (1.0, 1.0, 1.0); xf["quat"][0] = (0.0, 0.0, 0.0, 1.0)
+    return cam, xf
 assert BVH4_NODE.itemsize == 128 and PRIM_NODE.itemsize == 8
 assert AABB.itemsize == 24 and BVH2_NODE.itemsize == 32 and PRIMREF.itemsize == 28
 INVALID = 0xFFFFFFFF
@@ -39,7 +60,7 @@ ALGO_NAMES = {0: "TwoPassLbvh", 1: "SinglePassLbvh", 2: "PLOCNew", 3: "HPLOC"}
 EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
-    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_sah_cost",
+    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_sah_cost",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_version",
 ]
 
@@ -101,6 +122,8 @@ def lib() -> C.CDLL:
         "bvh_dev_alloc": ([vp, u64, C.POINTER(vp)], i32), "bvh_dev_free": ([vp, vp], i32),
         "bvh_dev_upload": ([vp, vp, vp, u64], i32), "bvh_dev_download": ([vp, vp, vp, u64], i32),
         "bvh_dev_copy": ([vp, vp, vp, u64], i32),
+        "bvh_generate_rays": ([vp, vp, vp, u32, u32], i32),
+        "bvh_trace_while": ([vp, vp, vp, vp, u32, u32, vp, vp, u32, u32], i32),
         "bvh_collapse4": ([vp, C.POINTER(Result), vp, vp, C.POINTER(u32)], i32),
         "bvh_ctx_kernel_times": ([vp, C.c_char_p, u32, C.POINTER(C.c_float), C.POINTER(u32), u32], i32),
         "bvh_version": ([], C.c_char_p),
@@ -276,6 +299,22 @@ class _Builder:
         _check(lib().bvh_collapse4(self._ctx.handle, C.byref(self.result), wide.ptr, prims.ptr, C.byref(nw)), "bvh_collapse4")
         out = wide.download(BVH4_NODE, nw.value), prims.download(PRIM_NODE, n), int(nw.value)
         wide.free(); prims.free()
+        return out
+
+    def render(self, tris_host: np.ndarray, camera: np.ndarray, transform: np.ndarray, width: int = 512):
+        """traverseBvh's image: GenerateRays + while-while traversal of this tree (through the LBVH-layout adapter for
+        PLOC/HPLOC).  Returns (rgba uint8[width*width*4], rays RAY[width*width])."""
+        ctx, n = self._ctx, self.result.n_leaves
+        d_tris = ctx.upload(tris_host)
+        d_nodes = ctx.alloc((2 * n - 1) * BVH2_NODE.itemsize)
+        _check(lib().bvh_to_lbvh_layout(ctx.handle, C.byref(self.result), d_nodes.ptr), "bvh_to_lbvh_layout")
+        d_rays = ctx.alloc(width * width * RAY.itemsize); d_rgba = ctx.alloc(width * width * 4)
+        cam = np.ascontiguousarray(camera); xf = np.ascontiguousarray(transform)
+        _check(lib().bvh_generate_rays(ctx.handle, cam.ctypes.data, d_rays.ptr, width, width), "bvh_generate_rays")
+        _check(lib().bvh_trace_while(ctx.handle, d_rays.ptr, d_tris.ptr, d_nodes.ptr, self.result.root, n - 1, xf.ctypes.data, d_rgba.ptr, width, width), "bvh_trace_while")
+        out = d_rgba.download(np.uint8, width * width * 4), d_rays.download(RAY, width * width)
+        for bfr in (d_tris, d_nodes, d_rays, d_rgba):
+            bfr.free()
         return out
 
     def to_lbvh_layout(self) -> np.ndarray:

@@ -97,7 +97,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
     c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);
-    c->small = k.take<u32>(64);
+    c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH, [16..31] camera, [32..47] transform
     *total = k.off;
 }
 
@@ -388,6 +388,26 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
         if (host[0] == host[1 + first]) { if (n_wide_out) *n_wide_out = host[0]; return 0; }
     }
     return BVH_E_INTERNAL;
+}
+
+// GenerateRays (src/CommonBlocksKernel.h:432-463): camera (64-byte Camera record, host pointer) -> Ray[width*height] on the device
+int bvh_generate_rays(bvh_ctx* c, const void* h_camera, void* d_rays, uint32_t width, uint32_t height) {
+    if (!c || !h_camera || !d_rays || !width || !height) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    HIP_TRY(hipMemcpyAsync(c->small + 16, h_camera, 64, hipMemcpyHostToDevice, c->stream));
+    launch_generate_rays(c->stream, c->small + 16, d_rays, width, height);
+    return herr(hipGetLastError());
+}
+// BvhTraversalWhile (src/TraversalKernel.h:238-335) over an LBVH-layout node array; d_rgba (width*height*4 bytes) is cleared first
+// (src/TwoPassLbvh.cpp:243: d_colorBuffer.reset()).
+int bvh_trace_while(bvh_ctx* c, const void* d_rays, const void* d_tris, const void* d_nodes_lbvh, uint32_t root, uint32_t n_internal,
+                    const void* h_transform, void* d_rgba, uint32_t width, uint32_t height) {
+    if (!c || !d_rays || !d_tris || !d_nodes_lbvh || !h_transform || !d_rgba || !width || width != height) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    HIP_TRY(hipMemcpyAsync(c->small + 32, h_transform, 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)width * height * 4, c->stream));
+    launch_trace_while(c->stream, d_rays, d_tris, d_nodes_lbvh, c->small + 32, d_rgba, root, width, height, n_internal);
+    return herr(hipGetLastError());
 }
 
 int bvh_sah_cost(bvh_ctx* c, const bvh_result* in, double* cost_out) {

@@ -82,6 +82,11 @@ void collapse_begin(hipStream_t s, uint2* d_taskq, uint32_t* d_state, uint32_t r
 void collapse_enqueue(hipStream_t s, const void* d_nodes, const void* d_leaves, void* d_wide, void* d_prims, uint2* d_taskq,
                       uint32_t* d_state, int first, int count, uint32_t n, int layout);
 
+// ---- consumer side (trace.hip)
+void launch_generate_rays(hipStream_t s, const void* d_cam, void* d_rays, uint32_t width, uint32_t height);
+void launch_trace_while(hipStream_t s, const void* d_rays, const void* d_tris, const void* d_nodes, const void* d_xf, void* d_rgba,
+                        uint32_t root, uint32_t width, uint32_t height, uint32_t n_internal);
+
 // ---- helpers (misc.hip)
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out);
 void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t root, uint32_t n, int layout, double* d_out /*[1], zeroed inside*/);

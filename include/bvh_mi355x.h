@@ -121,6 +121,16 @@ int  bvh_to_lbvh_layout(bvh_ctx* ctx, const bvh_result* in, void* d_nodes_2n_min
  * BVH2 -> BVH4.  d_bvh4: Bvh4Node[n] (128 B each, src/Common.h:560-566), d_primnodes: PrimNode[n] (src/Common.h:568-572);
  * wide root = node 0; *n_wide_out = number of wide nodes.  Blocking (reads the level bounds back). */
 int  bvh_collapse4(bvh_ctx* ctx, const bvh_result* in, void* d_bvh4, void* d_primnodes, uint32_t* n_wide_out);
+/* ---- consumer side used by the image check ---- */
+/* GenerateRays (src/CommonBlocksKernel.h:432-463).  h_camera: 64-byte Camera record (src/Common.h:550-558) on the host;
+ * d_rays: Ray[width*height] (32 bytes each, src/Common.h:533-539), ray of pixel (gx,gy) at index gx*height+gy. */
+int  bvh_generate_rays(bvh_ctx* ctx, const void* h_camera, void* d_rays, uint32_t width, uint32_t height);
+/* BvhTraversalWhile (src/TraversalKernel.h:238-335): while-while closest-hit traversal of an LBVH-layout Bvh2Node[2n-1] array
+ * (use bvh_to_lbvh_layout for PLOC/HPLOC results).  h_transform: 64-byte Transformation (src/Common.h:541-548) on the host.
+ * d_rgba: width*height*4 bytes, cleared, then u8 (u*255, v*255, (1-u-v)*255, 255) per hit pixel at index gx*width+gy.
+ * Square images only (the reference indexes rays with height and pixels with width). */
+int  bvh_trace_while(bvh_ctx* ctx, const void* d_rays, const void* d_tris, const void* d_nodes_lbvh, uint32_t root, uint32_t n_internal,
+                     const void* h_transform, void* d_rgba, uint32_t width, uint32_t height);
 /* BVH2 SAH cost with the formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349), device reduction, f64. */
 int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
 /* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL */

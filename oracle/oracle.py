@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
         L.orc_sah_binned.argtypes = [vp, u32, u32, C.POINTER(C.c_float)]; L.orc_sah_binned.restype = C.c_double
         L.orc_collapse4.argtypes = [vp, vp, u32, u32, C.c_int, vp, vp]; L.orc_collapse4.restype = u32
         L.orc_topology_hash4.argtypes = [vp, vp, u32, u32]; L.orc_topology_hash4.restype = u64
+        L.orc_generate_rays.argtypes = [vp, vp, u32, u32]
+        L.orc_trace_while.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, C.POINTER(u32)]
         L.orc_sah_bvh4.argtypes = [vp, vp, vp, u32, u32, C.POINTER(C.c_float)]; L.orc_sah_bvh4.restype = C.c_double
         _lib = L
     return _lib
@@ -208,6 +210,23 @@ def collapse4(nodes, leaves, root, n, layout):
     return w, pn, int(total)
 
 
+RAY = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("tmin", "<f4"), ("tmax", "<f4")])
+
+
+def generate_rays(camera: np.ndarray, width: int, height: int) -> np.ndarray:
+    rays = np.zeros(width * height, dtype=RAY)
+    lib().orc_generate_rays(np.ascontiguousarray(camera).ctypes.data, rays.ctypes.data, width, height)
+    return rays
+
+
+def trace_while(rays, tris, nodes_lbvh, transform, root, width, n_internal):
+    """-> (rgba uint8[width*width*4], rays whose stack exceeded the reference's 32 entries)"""
+    rgba = np.zeros(width * width * 4, dtype=np.uint8); ov = C.c_uint32()
+    lib().orc_trace_while(np.ascontiguousarray(rays).ctypes.data, tris.ctypes.data, np.ascontiguousarray(nodes_lbvh).ctypes.data,
+                          np.ascontiguousarray(transform).ctypes.data, rgba.ctypes.data, root, width, width, n_internal, C.byref(ov))
+    return rgba, int(ov.value)
+
+
 def topology_hash4(w, pn, total, n) -> int:
     return int(lib().orc_topology_hash4(np.ascontiguousarray(w).ctypes.data, np.ascontiguousarray(pn).ctypes.data, total, n))
 
@@ -263,6 +282,8 @@ def ref_driver(nofma: bool = False):
     L.refdrv_lbvh_single.argtypes = [vp, u32, vp, vp, vp, C.POINTER(u32)]
     L.refdrv_lbvh_two.argtypes = [vp, u32, vp, vp, vp]
     L.refdrv_hploc.argtypes = [vp, u32, vp, vp, vp, vp, C.POINTER(u32), C.c_int]
+    L.refdrv_generate_rays.argtypes = [vp, vp, u32, u32]
+    L.refdrv_trace_while.argtypes = [vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32]
     rc = L.refdrv_init(os.path.join(_HERE, "_ref").encode(), int(nofma))
     if rc != 0:
         raise RuntimeError("refdrv_init: " + L.refdrv_error().decode())
@@ -309,3 +330,19 @@ def ref_hploc(boxes, skeys, svals, nofma=False, cover_all=False):
     nodes = np.zeros(max(n - 1, 1), dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); merged = C.c_uint32()
     _rc(L, L.refdrv_hploc(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, C.byref(merged), int(cover_all)), "refdrv_hploc")
     return nodes[: n - 1], leaves, int(merged.value)
+
+
+def ref_generate_rays(camera, width, height, nofma=False):
+    L = ref_driver(nofma); _reinit(L, nofma)
+    rays = np.zeros(width * height, dtype=RAY)
+    _rc(L, L.refdrv_generate_rays(np.ascontiguousarray(camera).ctypes.data, rays.ctypes.data, width, height), "refdrv_generate_rays")
+    return rays
+
+
+def ref_trace_while(rays, tris, nodes_lbvh, transform, root, width, n_internal, nofma=False):
+    L = ref_driver(nofma); _reinit(L, nofma)
+    rgba = np.zeros(width * width * 4, dtype=np.uint8)
+    nodes_lbvh = np.ascontiguousarray(nodes_lbvh)
+    _rc(L, L.refdrv_trace_while(np.ascontiguousarray(rays).ctypes.data, tris.ctypes.data, tris.shape[0], nodes_lbvh.ctypes.data, nodes_lbvh.shape[0],
+                                np.ascontiguousarray(transform).ctypes.data, rgba.ctypes.data, root, width, width, n_internal), "refdrv_trace_while")
+    return rgba

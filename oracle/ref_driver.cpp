@@ -20,7 +20,7 @@
 namespace {
 using u32 = uint32_t;
 struct Mod { hipModule_t m = nullptr; };
-Mod g_common, g_single, g_two, g_hploc;
+Mod g_common, g_single, g_two, g_hploc, g_trav;
 std::string g_err;
 
 #define RT(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return -(int)e_; } } while (0)
@@ -67,6 +67,7 @@ int refdrv_init(const char* dir, int nofma) {
     TRY(load(g_single, d + "/SinglePassLbvhKernel" + sfx));
     TRY(load(g_two, d + "/TwoPassLbvhKernel" + sfx));
     TRY(load(g_hploc, d + "/HplocKernel" + sfx));
+    TRY(load(g_trav, d + "/TraversalKernel" + sfx));
     return 0;
 }
 
@@ -124,6 +125,32 @@ int refdrv_hploc(const void* h_boxes, u32 n, const u32* h_skeys, const u32* h_sv
     { void* a[] = { &nodes.p, &leaves.p, &skeys.p, &idx.p, &parent.p, &cnt.p, &ncl, &nint }; TRY(launch(g_hploc.m, "HPloc", cover_all ? n : ni, 32, a)); }
     RT(hipDeviceSynchronize());
     TRY(nodes.down(h_nodes)); TRY(leaves.down(h_leaves)); TRY(cnt.down(merged));
+    return 0;
+}
+
+// GenerateRays (src/CommonBlocksKernel.h:432-463); host: src/TwoPassLbvh.cpp:225-242 (8x8 workgroups)
+int refdrv_generate_rays(const void* h_camera, void* h_rays, u32 width, u32 height) {
+    Dev<B64> cam; Dev<B32> rays;
+    TRY(cam.alloc(1)); TRY(cam.up(h_camera)); TRY(rays.alloc((size_t)width * height, 0));
+    hipFunction_t fn; RT(hipModuleGetFunction(&fn, g_common.m, "GenerateRays"));
+    void* a[] = { &cam.p, &rays.p, &width, &height };
+    RT(hipModuleLaunchKernel(fn, (width + 7) / 8, (height + 7) / 8, 1, 8, 8, 1, 0, nullptr, a, nullptr));
+    RT(hipDeviceSynchronize());
+    TRY(rays.down(h_rays));
+    return 0;
+}
+
+// BvhTraversalWhile (src/TraversalKernel.h:238-335); host launch shape as src/TwoPassLbvh.cpp:275-294
+int refdrv_trace_while(const void* h_rays, const void* h_tris, u32 n_tris, const void* h_nodes, u32 n_nodes, const void* h_transform,
+                       unsigned char* h_rgba, u32 root, u32 width, u32 height, u32 n_internal) {
+    Dev<B32> rays, nodes; Dev<B64> tris, xf; Dev<unsigned char> rgba;
+    TRY(rays.alloc((size_t)width * height)); TRY(rays.up(h_rays)); TRY(tris.alloc(n_tris)); TRY(tris.up(h_tris));
+    TRY(nodes.alloc(n_nodes)); TRY(nodes.up(h_nodes)); TRY(xf.alloc(1)); TRY(xf.up(h_transform)); TRY(rgba.alloc((size_t)width * height * 4, 0));
+    hipFunction_t fn; RT(hipModuleGetFunction(&fn, g_trav.m, "BvhTraversalWhile"));
+    void* a[] = { &rays.p, &tris.p, &nodes.p, &xf.p, &rgba.p, &root, &width, &height, &n_internal };
+    RT(hipModuleLaunchKernel(fn, (width + 7) / 8, (height + 7) / 8, 1, 8, 8, 1, 0, nullptr, a, nullptr));
+    RT(hipDeviceSynchronize());
+    TRY(rgba.down(h_rgba));
     return 0;
 }
 
