@@ -61,7 +61,7 @@ EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_sah_cost",
-    "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_version",
+    "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
 
 
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
         "bvh_dev_alloc": ([vp, u64, C.POINTER(vp)], i32), "bvh_dev_free": ([vp, vp], i32),
         "bvh_dev_upload": ([vp, vp, vp, u64], i32), "bvh_dev_download": ([vp, vp, vp, u64], i32),
         "bvh_dev_copy": ([vp, vp, vp, u64], i32),
+        "bvh_batched_build": ([i32, C.POINTER(i32), i32, C.POINTER(vp), C.POINTER(u32), i32, C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "bvh_generate_rays": ([vp, vp, vp, u32, u32], i32),
         "bvh_trace_while": ([vp, vp, vp, vp, u32, u32, vp, vp, u32, u32], i32),
         "bvh_collapse4": ([vp, C.POINTER(Result), vp, vp, C.POINTER(u32)], i32),
@@ -343,5 +344,16 @@ class HPLOC(_Builder):
 
 
 from .batched import BatchedBuildInput, BatchedBvhBuilder, shard  # noqa: E402,F401
+
+def batched_build(meshes, algo: int = ALGO_HPLOC, devices=(0,)):
+    """bvh_batched_build: single-process multi-GPU scene shard -> (root_aabbs (M,6) float32, build ms per mesh)"""
+    m = len(meshes)
+    arrs = [np.ascontiguousarray(t) for t in meshes]
+    ptrs = (C.c_void_p * m)(*[a.ctypes.data for a in arrs]); counts = (C.c_uint32 * m)(*[a.shape[0] for a in arrs])
+    devs = (C.c_int * len(devices))(*devices)
+    roots = np.zeros((m, 6), dtype=np.float32); ms = np.zeros(m, dtype=np.float32)
+    _check(lib().bvh_batched_build(len(devices), devs, algo, ptrs, counts, m, roots.ctypes.data_as(C.POINTER(C.c_float)), ms.ctypes.data_as(C.POINTER(C.c_float))), "bvh_batched_build")
+    return roots, ms
+
 
 BUILDERS = {ALGO_TWOPASS: TwoPassLbvh, ALGO_SINGLEPASS: SinglePassLbvh, ALGO_PLOCPP: PLOCNew, ALGO_HPLOC: HPLOC}

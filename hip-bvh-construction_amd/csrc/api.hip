@@ -83,7 +83,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->boxes = k.take<bvh_aabb>(n);
     c->scene = k.take<float>(8);
     c->keys = k.take<u32>(n); c->skeys = k.take<u32>(n); c->svals = k.take<u32>(n);
-    c->sort.tmp_keys = k.take<u32>(n); c->sort.tmp_vals = k.take<u32>(n);
+    c->sort.pairs0 = k.take<u64>(n); c->sort.pairs1 = k.take<u64>(n);
     c->sort.hist = k.take<u32>(SORT_MAX_PASSES * SORT_RADIX);
     c->sort.status = k.take<u32>(sort_status_bytes(cap) / sizeof(u32));
     c->sort.counters = k.take<u32>(SORT_MAX_PASSES);

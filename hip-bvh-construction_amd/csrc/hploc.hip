@@ -329,7 +329,13 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hp_plan(const u32* __restrict__ sk
 }
 
 // level_offsets: the sort's exclusive digit offsets (hist after k_scan_hist): tasks of level v are task_ids[off[v] .. off[v+1])
-__global__ __launch_bounds__(HP_BLOCK) void k_hp_level(const u32* __restrict__ level_offsets, int level, const u32* __restrict__ task_ids,
+#ifndef HP_LEVEL_WAVES
+#define HP_LEVEL_WAVES 1
+#endif
+#ifndef HP_LEVEL_PIPELINE
+#define HP_LEVEL_PIPELINE 0
+#endif
+__global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32* __restrict__ level_offsets, int level, const u32* __restrict__ task_ids,
                                                        const u64* __restrict__ ranges, const bvh_aabb* __restrict__ boxes,
                                                        const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
                                                        u64* cidx, u32* zero_parent, u32 n) {
@@ -339,9 +345,10 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hp_level(const u32* __restrict__ l
     const u32 ni = n - 1;
     const u32 stride = gridDim.x * (HP_BLOCK / 32);
     const u32 t0 = blockIdx.x * (HP_BLOCK / 32) + (threadIdx.x >> 6) * 2;          // wave-uniform first task of the wave
-    // Software pipeline over the wave's tasks: task id three iterations ahead, its range two ahead, its cluster entries
-    // (survivor ids or the leaves' primitive indices) one ahead — so an iteration's own critical path is one gather
-    // (boxes) + the merge rounds; the dependent id -> range -> entry loads of later tasks are in flight meanwhile.
+#if HP_LEVEL_PIPELINE
+    // Software pipeline over the wave's tasks: task id three iterations ahead, its range two ahead, its cluster entries one
+    // ahead.  Measured on MI355X: no gain over the plain loop (the level kernels are issue-bound in the merge rounds, not
+    // latency-bound on these loads) and 12 more VGPRs; kept for reference, off by default.
     auto task_at = [&](u32 k) -> u32 { const u32 t = t0 + k * stride + (u32)half; return t < count ? task_ids[base + t] : INV; };
     auto range_of = [&](u32 p) -> u64 { return p != INV ? ranges[p] : 0ull; };
     u32 p0 = task_at(0), p1 = task_at(1), p2 = task_at(2);
@@ -354,6 +361,15 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hp_level(const u32* __restrict__ l
         merge_exec<false>(p0 != INV, (u32)r0, (u32)(r0 >> 32), e0, boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
         p0 = p1; r0 = r1; e0 = e1; p1 = p2; r1 = r2; p2 = p3;
     }
+#else
+    for (u32 tw = t0; tw < count; tw += stride) {                                   // wave-uniform
+        const u32 t = tw + (u32)half;
+        const bool have = t < count;
+        u32 tL = 0, tR = 0, tP = 0;
+        if (have) { tP = task_ids[base + t]; const u64 rg = ranges[tP]; tL = (u32)rg; tR = (u32)(rg >> 32); }
+        merge_exec<false>(have, tL, tR, load_entry<false>(have, tL, tR, tP, svals, cidx, ni, slot), boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
+    }
+#endif
 }
 
 void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,

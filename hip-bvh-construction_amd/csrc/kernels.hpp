@@ -29,12 +29,15 @@ void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d
 constexpr int SORT_BITS = 8;
 constexpr int SORT_RADIX = 1 << SORT_BITS;
 constexpr int SORT_BLOCK = 256;
-constexpr int SORT_IPT = 16;                                  // keys per thread
+#ifndef BVH_SORT_IPT
+#define BVH_SORT_IPT 16
+#endif
+constexpr int SORT_IPT = BVH_SORT_IPT;                        // keys per thread
 constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup
 constexpr int SORT_MAX_PASSES = 4;
 struct SortScratch {
-    uint32_t* tmp_keys;      // u32[n]
-    uint32_t* tmp_vals;      // u32[n]
+    uint64_t* pairs0;        // u64[n] interleaved {key,value} ping
+    uint64_t* pairs1;        // u64[n] pong
     uint32_t* hist;          // u32[SORT_MAX_PASSES * SORT_RADIX]   (zeroed by sort_prepare)
     uint32_t* status;        // u32[SORT_MAX_PASSES * tiles * SORT_RADIX] (zeroed by sort_prepare)
     uint32_t* counters;      // u32[SORT_MAX_PASSES]                 (zeroed by sort_prepare)

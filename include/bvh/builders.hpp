@@ -106,6 +106,24 @@ public:
 };
 }  // namespace detail
 
+// src/BatchedBuilder.h:12-31, re-purposed as the scene shard of BASELINE.json config 5: one mesh per GPU, RCCL all-gather of roots
+struct BatchedBuildInput { std::vector<Triangle> m_primitives; };
+class BatchedBvhBuilder {
+public:
+    explicit BatchedBvhBuilder(std::vector<int> devices = {0}, bvh_algo algo = BVH_HPLOC) : m_devices(std::move(devices)), m_algo(algo) {}
+    void build(Context&, std::vector<BatchedBuildInput>& batch) {
+        std::vector<const void*> ptrs; std::vector<uint32_t> counts;
+        for (auto& b : batch) { ptrs.push_back(b.m_primitives.data()); counts.push_back((uint32_t)b.m_primitives.size()); }
+        m_rootAabbs.assign(batch.size(), Aabb{}); m_buildMs.assign(batch.size(), 0.f);
+        check(bvh_batched_build((int)m_devices.size(), m_devices.data(), m_algo, ptrs.data(), counts.data(), (int)batch.size(),
+                                reinterpret_cast<float*>(m_rootAabbs.data()), m_buildMs.data()), "bvh_batched_build");
+    }
+    std::vector<Aabb> m_rootAabbs;      // TLAS input: one root box per mesh, identical on every device after the all-gather
+    std::vector<float> m_buildMs;
+private:
+    std::vector<int> m_devices; bvh_algo m_algo;
+};
+
 class TwoPassLbvh : public detail::Builder<BVH_LBVH_TWOPASS> {};        // src/TwoPassLbvh.h:12-32
 class SinglePassLbvh : public detail::Builder<BVH_LBVH_SINGLEPASS> {};  // src/SinglePassLbvh.h:12-32
 class PLOCNew : public detail::Builder<BVH_PLOCPP> {};                  // src/PLOC++Bvh.h:12-33

@@ -137,6 +137,13 @@ int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
 int  bvh_download(bvh_ctx* ctx, const bvh_result* in, void* h_nodes, void* h_leaves, uint32_t* h_sorted_keys,
                   uint32_t* h_sorted_vals, void* h_scene_extent);
 
+/* BatchedBvhBuilder::build (src/BatchedBuilder.h:12-31) re-purposed as the multi-GPU scene shard (BASELINE.json config 5), one
+ * process: mesh m -> devs[m % n_dev], one ctx + host thread per device, then ONE RCCL all-gather of the root AABBs.
+ * h_tris[m]: host Triangle[n_tris[m]].  root_aabbs_out: 6 floats per mesh (min xyz, max xyz).  build_ms_out (optional):
+ * E+M+S+B milliseconds per mesh.  Blocking. */
+int  bvh_batched_build(int n_dev, const int* devs, bvh_algo algo, const void* const* h_tris, const uint32_t* n_tris, int n_meshes,
+                       float* root_aabbs_out, float* build_ms_out);
+
 /* wait for everything enqueued on the ctx's stream (bvh_build is asynchronous unless it has to read something back:
  * profiling on, single-pass root index, PLOC++ iteration batches) */
 int  bvh_ctx_synchronize(bvh_ctx* ctx);

@@ -164,3 +164,46 @@ def test_collapse4(pkg, orc, ctx, cases, name, algo):
             assert R.ref_checkLBvh4Correctness(w.ctypes.data, p.ctypes.data, 0, n - 1) == 1
         # f32 accumulation in node-index order, exactly as the reference does it (the f64 value differs by accumulated rounding)
         assert R.ref_calculatebvh4Cost(w.ctypes.data, p.ctypes.data, boxes.ctypes.data, 0, total, n - 1) == pytest.approx(orc.sah_bvh4(wide, prims, boxes, total, n)[1], rel=1e-6)
+
+
+def test_batched_build_single_process(pkg, orc):
+    """bvh_batched_build (C ABI): meshes sharded over the visible devices, roots all-gathered with RCCL"""
+    import torch
+    devs = tuple(range(torch.cuda.device_count()))
+    meshes = [pkg.meshgen.uniform(3000 + 500 * m, 40 + m, offset=(float(m), 0.0, 0.0)) for m in range(5)]
+    roots, ms = pkg.batched_build(meshes, pkg.ALGO_HPLOC, devs)
+    for m, t in enumerate(meshes):
+        _, scene = orc.prim_bounds(t)
+        assert np.array_equal(roots[m], np.concatenate([scene["min"][0], scene["max"][0]]))
+    assert (ms > 0).all()
+
+
+@pytest.mark.parametrize("name", ["uniform_1000", "uniform_50k", "dups_3000"])
+def test_stage_level_emitters(pkg, orc, ctx, cases, name):
+    """the per-kernel C-ABI entry points (bvh_emit_*) fed with the oracle's sorted arrays, outputs into caller buffers"""
+    import ctypes as C
+    tris = cases[name]; n = len(tris)
+    fe = orc.front_end(tris)
+    L = pkg.lib()
+    d_box, d_k, d_v = _dev(ctx, fe["boxes"]), _dev(ctx, fe["skeys"]), _dev(ctx, fe["svals"])
+    d_nodes = ctx.alloc((2 * n - 1) * 32); d_leaves = ctx.alloc(n * 28)
+    root = C.c_uint32()
+    assert L.bvh_emit_lbvh_single(ctx.handle, d_box.ptr, d_k.ptr, d_v.ptr, n, d_nodes.ptr, C.byref(root)) == 0
+    ref, oroot = orc.lbvh_single(tris, fe["skeys"], fe["svals"])
+    assert root.value == oroot and d_nodes.download(pkg.BVH2_NODE, 2 * n - 1).tobytes() == ref.tobytes()
+    assert L.bvh_emit_lbvh_two(ctx.handle, d_box.ptr, d_k.ptr, d_v.ptr, n, d_nodes.ptr) == 0
+    ctx.synchronize()
+    assert d_nodes.download(pkg.BVH2_NODE, 2 * n - 1).tobytes() == orc.lbvh_two(tris, fe["skeys"], fe["svals"])[0].tobytes()
+    it = C.c_uint32()
+    assert L.bvh_emit_ploc(ctx.handle, d_box.ptr, d_v.ptr, n, d_nodes.ptr, d_leaves.ptr, C.byref(it)) == 0
+    pn, pl, st = orc.ploc(fe["boxes"], fe["svals"])
+    assert d_nodes.download(pkg.BVH2_NODE, n - 1).tobytes() == pn.tobytes() and d_leaves.download(pkg.PRIMREF, n).tobytes() == pl.tobytes()
+    assert it.value == st["iterations"]
+    assert L.bvh_emit_hploc(ctx.handle, d_box.ptr, d_k.ptr, d_v.ptr, n, d_nodes.ptr, d_leaves.ptr) == 0
+    ctx.synchronize()
+    hn, hl, _ = orc.hploc(fe["boxes"], fe["skeys"], fe["svals"])
+    gn, gl = d_nodes.download(pkg.BVH2_NODE, n - 1), d_leaves.download(pkg.PRIMREF, n)
+    assert gl.tobytes() == hl.tobytes() and orc.topology_hash(gn, gl, 0, n, 1) == orc.topology_hash(hn, hl, 0, n, 1)
+    # argument validation (no GPU work): the reference's kernels have no checks; the ABI returns BVH_E_INVALID_ARG
+    assert L.bvh_emit_hploc(ctx.handle, None, d_k.ptr, d_v.ptr, n, d_nodes.ptr, d_leaves.ptr) == -10001
+    assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_k.ptr, d_v.ptr, 5, 40) == -10001
