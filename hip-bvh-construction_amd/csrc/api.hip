@@ -285,7 +285,7 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    if (use_levels(n)) launch_hploc_levels(c->stream, c->sort, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, c->small + 1);
+    if (use_levels(n)) launch_hploc_levels(c->stream, c->sort, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, reinterpret_cast<uint4*>(c->sort.pairs0), c->small + 1);
     else launch_hploc(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
     return herr(hipGetLastError());
 }
@@ -323,7 +323,7 @@ int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_
     switch (algo) {
         case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->slots, c->small); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->parent, c->flags); break;
-        case BVH_HPLOC:           if (use_levels(n)) launch_hploc_levels(s, c->sort, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, c->small + 1);
+        case BVH_HPLOC:           if (use_levels(n)) launch_hploc_levels(s, c->sort, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, reinterpret_cast<uint4*>(c->sort.pairs0), c->small + 1);
                                   else launch_hploc(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);

@@ -104,15 +104,17 @@ __device__ __forceinline__ HpEntry load_entry(bool have, u32 tL, u32 tR, u32 tP,
         return en;
 }
 
+struct HpWork { u32 id, rep, cnt, tL; Box b; bool have, final_; };
+
+// left-pack the loaded entries, fetch their boxes (leaves: fused SetupClusters), return the work list of this half
 template <bool AGENT>
-__device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
-                                           const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
-                                           u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
-        const bool final_ = have && tL == 0 && tR == ni;
+__device__ __forceinline__ HpWork prepare(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
+                                          const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, const bvh2_node* nodes,
+                                          u32 ni, int slot, int hbase) {
         u32 id = en.id, rep = en.rep, prim = en.prim;
         const u32 vb = (u32)(__ballot(id != INV) >> hbase);
         const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
-        u32 cnt = nl + nr;
+        const u32 cnt = nl + nr;
         {   // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
             const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
             const u32 ti = (u32)__shfl((int)id, src), tr = (u32)__shfl((int)rep, src), tp = (u32)__shfl((int)prim, src);
@@ -128,6 +130,17 @@ __device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en
                 f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
             } else b = node_box<AGENT>(nodes + id);                                                  // :242-246
         }
+        HpWork w; w.id = id; w.rep = rep; w.cnt = cnt; w.tL = tL; w.b = b; w.have = have; w.final_ = have && tL == 0 && tR == ni;
+        return w;
+}
+
+// PLOC rounds until <= 16 clusters (root: 1) remain, then storeIndices
+template <bool AGENT>
+__device__ __forceinline__ void reduce_and_store(HpWork w, bvh2_node* nodes, u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
+        const bool have = w.have, final_ = w.final_;
+        const u32 tL = w.tL;
+        u32 id = w.id, rep = w.rep, cnt = w.cnt;
+        Box b = w.b;
         const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
         while (__ballot(have && cnt > threshold)) {
             const bool act = have && cnt > threshold;
@@ -190,7 +203,13 @@ __device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en
         }
         // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
         if (have && !final_ && slot < 16) st_e<AGENT>(cidx + tL + slot, entry(id, rep));
+}
 
+template <bool AGENT>
+__device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
+                                           const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
+                                           u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
+    reduce_and_store<AGENT>(prepare<AGENT>(have, tL, tR, en, boxes, svals, leaves, nodes, ni, slot, hbase), nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
 }
 
 #ifndef HP_WAVES
@@ -328,15 +347,22 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hp_plan(const u32* __restrict__ sk
     if (big) ranges[pc] = (u64)(u32)lo | ((u64)(u32)hi << 32);
 }
 
-// level_offsets: the sort's exclusive digit offsets (hist after k_scan_hist): tasks of level v are task_ids[off[v] .. off[v+1])
+// task records in level order: {gap, L, R, -} — one 16-byte load instead of the dependent task id -> range pair
+__global__ __launch_bounds__(256) void k_hp_pack(const u32* __restrict__ level_offsets, const u32* __restrict__ task_ids,
+                                                 const u64* __restrict__ ranges, uint4* __restrict__ tasks) {
+    const u32 total = level_offsets[62];                      // end of the last level (key 255 = "no task" sorts behind)
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const u32 p = task_ids[i]; const u64 rg = ranges[p];
+        tasks[i] = make_uint4(p, (u32)rg, (u32)(rg >> 32), 0u);
+    }
+}
+
+// level_offsets: the sort's exclusive digit offsets (hist after k_scan_hist): tasks of level v are tasks[off[v] .. off[v+1])
 #ifndef HP_LEVEL_WAVES
 #define HP_LEVEL_WAVES 1
 #endif
-#ifndef HP_LEVEL_PIPELINE
-#define HP_LEVEL_PIPELINE 0
-#endif
-__global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32* __restrict__ level_offsets, int level, const u32* __restrict__ task_ids,
-                                                       const u64* __restrict__ ranges, const bvh_aabb* __restrict__ boxes,
+__global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32* __restrict__ level_offsets, int level, const uint4* __restrict__ tasks,
+                                                       const bvh_aabb* __restrict__ boxes,
                                                        const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
                                                        u64* cidx, u32* zero_parent, u32 n) {
     const u32 base = level_offsets[level], count = level_offsets[level + 1] - base;
@@ -345,31 +371,23 @@ __global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32
     const u32 ni = n - 1;
     const u32 stride = gridDim.x * (HP_BLOCK / 32);
     const u32 t0 = blockIdx.x * (HP_BLOCK / 32) + (threadIdx.x >> 6) * 2;          // wave-uniform first task of the wave
-#if HP_LEVEL_PIPELINE
-    // Software pipeline over the wave's tasks: task id three iterations ahead, its range two ahead, its cluster entries one
-    // ahead.  Measured on MI355X: no gain over the plain loop (the level kernels are issue-bound in the merge rounds, not
-    // latency-bound on these loads) and 12 more VGPRs; kept for reference, off by default.
-    auto task_at = [&](u32 k) -> u32 { const u32 t = t0 + k * stride + (u32)half; return t < count ? task_ids[base + t] : INV; };
-    auto range_of = [&](u32 p) -> u64 { return p != INV ? ranges[p] : 0ull; };
-    u32 p0 = task_at(0), p1 = task_at(1), p2 = task_at(2);
-    u64 r0 = range_of(p0), r1 = range_of(p1);
-    HpEntry e0 = load_entry<false>(p0 != INV, (u32)r0, (u32)(r0 >> 32), p0, svals, cidx, ni, slot);
-    for (u32 k = 0; t0 + k * stride < count; ++k) {
-        const u32 p3 = task_at(k + 3);
-        const u64 r2 = range_of(p2);
-        const HpEntry e1 = load_entry<false>(p1 != INV, (u32)r1, (u32)(r1 >> 32), p1, svals, cidx, ni, slot);
-        merge_exec<false>(p0 != INV, (u32)r0, (u32)(r0 >> 32), e0, boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
-        p0 = p1; r0 = r1; e0 = e1; p1 = p2; r1 = r2; p2 = p3;
+    // The merge rounds are short next to the dependent loads in front of them (task record -> cluster entries -> boxes;
+    // measured: waves parked on s_waitcnt 66 % of the time), and the compiler serialises loads prefetched across the loop
+    // back-edge.  So every iteration carries TWO independent task pairs (A, B): their loads are issued stage by stage
+    // together, then the rounds run back to back — twice the memory-level parallelism per wave.
+    for (u32 tw = t0; tw < count; tw += 2 * stride) {                                // wave-uniform
+        const u32 tA = tw + (u32)half, tB = tw + stride + (u32)half;
+        const bool hA = tA < count, hB = tB < count;
+        uint4 rA = make_uint4(0, 0, 0, 0), rB = make_uint4(0, 0, 0, 0);
+        if (hA) rA = tasks[base + tA];
+        if (hB) rB = tasks[base + tB];
+        const HpEntry eA = load_entry<false>(hA, rA.y, rA.z, rA.x, svals, cidx, ni, slot);
+        const HpEntry eB = load_entry<false>(hB, rB.y, rB.z, rB.x, svals, cidx, ni, slot);
+        const HpWork wA = prepare<false>(hA, rA.y, rA.z, eA, boxes, svals, leaves, nodes, ni, slot, hbase);
+        const HpWork wB = prepare<false>(hB, rB.y, rB.z, eB, boxes, svals, leaves, nodes, ni, slot, hbase);
+        reduce_and_store<false>(wA, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
+        reduce_and_store<false>(wB, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
     }
-#else
-    for (u32 tw = t0; tw < count; tw += stride) {                                   // wave-uniform
-        const u32 t = tw + (u32)half;
-        const bool have = t < count;
-        u32 tL = 0, tR = 0, tP = 0;
-        if (have) { tP = task_ids[base + t]; const u64 rg = ranges[tP]; tL = (u32)rg; tR = (u32)(rg >> 32); }
-        merge_exec<false>(have, tL, tR, load_entry<false>(have, tL, tR, tP, svals, cidx, ni, slot), boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
-    }
-#endif
 }
 
 void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,
@@ -389,17 +407,18 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, c
 // Level-synchronous HPLOC for large n.  level_keys / task_keys / task_ids: u32[n] scratch; sc: the sort's scratch (re-armed here).
 void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                          void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
-                         uint32_t* d_task_keys, uint32_t* d_task_ids, uint32_t* d_zero_parent) {
+                         uint32_t* d_task_keys, uint32_t* d_task_ids, uint4* d_tasks, uint32_t* d_zero_parent) {
     const u32 gaps = n - 1;
     { KernelScope ks(s, "k_hp_plan"); hipLaunchKernelGGL(k_hp_plan, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, d_skeys, d_ranges, d_level_keys, n); }
     sort_prepare(s, sc, gaps);
     sort_pairs(s, sc, d_level_keys, nullptr, gaps, d_task_keys, d_task_ids, 0, 8, false);     // one pass; sc.hist = level offsets
+    hipLaunchKernelGGL(k_hp_pack, dim3(1024), dim3(256), 0, s, (const u32*)sc.hist, (const u32*)d_task_ids, (const u64*)d_ranges, d_tasks);
     const u32 max_tasks = gaps / 17 + 1;
     u32 grid = (max_tasks + (HP_BLOCK / 32) - 1) / (HP_BLOCK / 32);
     if (grid > 2048u) grid = 2048u;
     KernelScope ks(s, "k_hp_level");                  // all 62 launches are timed as one group
     for (int level = 0; level < 62; ++level) {       // level = 63 - c0, c0 in [2, 63]
-        hipLaunchKernelGGL(k_hp_level, dim3(grid), dim3(HP_BLOCK), 0, s, (const u32*)sc.hist, level, (const u32*)d_task_ids, (const u64*)d_ranges,
+        hipLaunchKernelGGL(k_hp_level, dim3(grid), dim3(HP_BLOCK), 0, s, (const u32*)sc.hist, level, (const uint4*)d_tasks,
                            (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_zero_parent, n);
     }
 }
