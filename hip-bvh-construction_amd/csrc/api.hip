@@ -93,7 +93,8 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->parent = k.take<u32>(2 * n);
     c->flags = k.take<u32>(n);
     c->cidx = k.take<u32>(n);
-    c->ploc.ids0 = c->cidx;
+    c->ploc.list0 = k.take<uint4>(2 * n);
+    c->ploc.list1 = k.take<uint4>(2 * n);
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
     c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);

@@ -63,8 +63,9 @@ void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_box
                          void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
                          uint32_t* d_task_keys, uint32_t* d_task_ids, uint4* d_tasks /*uint4[n/17+1]*/, uint32_t* d_zero_parent);
 struct PlocScratch {
-    uint32_t* ids0;          // u32[n]
-    uint32_t* ids1;          // u32[n]
+    void*     list0;         // 32-byte cluster entries {id, box} x n (ping)
+    void*     list1;         // pong
+    uint32_t* ids1;          // u32[n] general scratch (HPLOC level mode: task ids)
     uint64_t* status;        // u64[PLOC_MAX_ITERS * chunks]
     uint32_t* state;         // u32[PLOC_STATE_WORDS]
 };

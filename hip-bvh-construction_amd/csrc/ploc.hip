@@ -35,8 +35,29 @@ __device__ __forceinline__ Box lds_box(const PlocLds& s, int k) { return { s.lx[
 __device__ __forceinline__ void lds_set(PlocLds& s, int k, u32 id, const Box& b) {
     s.id[k] = id; s.lx[k] = b.lx; s.ly[k] = b.ly; s.lz[k] = b.lz; s.hx[k] = b.hx; s.hy[k] = b.hy; s.hz[k] = b.hz;
 }
-__device__ __forceinline__ Box cluster_box(u32 id, u32 ni, const bvh_primref* __restrict__ leaves, const bvh2_node* __restrict__ nodes) {
-    return id >= ni ? box_load(&leaves[id - ni].aabb) : box_load(&nodes[id].aabb);   // :237-241 (nodes of earlier launches)
+// The cluster list carries the boxes: one 32-byte entry {id, box, pad} per cluster, read and written as two float4.  The
+// reference keeps ids only and gathers every cluster's box from the leaf / node arrays in every iteration (:237-241) — on
+// HBM a random 24..32-byte gather costs a full sector and a dependent round trip; streaming 32 B/cluster does not.
+__device__ __forceinline__ void entry_load(const float4* __restrict__ list, size_t g, u32& id, Box& b) {
+    const float4 a = list[2 * g], c = list[2 * g + 1];
+    id = __float_as_uint(a.x); b = { a.y, a.z, a.w, c.x, c.y, c.z };
+}
+__device__ __forceinline__ void entry_store(float4* __restrict__ list, size_t g, u32 id, const Box& b) {
+    list[2 * g] = make_float4(__uint_as_float(id), b.lx, b.ly, b.lz);
+    list[2 * g + 1] = make_float4(b.hx, b.hy, b.hz, 0.0f);
+}
+
+// SetupClusters (:39-55): leaf records + the initial cluster list
+__global__ __launch_bounds__(256) void k_ploc_setup(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals,
+                                                    bvh_primref* __restrict__ leaves, float4* __restrict__ list, u32 n) {
+    const u32 g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const u32 prim = svals[g];
+    const Box b = box_load(boxes + prim);
+    float* f = reinterpret_cast<float*>(leaves + g);
+    reinterpret_cast<u32*>(f)[0] = prim;
+    f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+    entry_store(list, g, g + (n - 1), b);
 }
 
 // nearest neighbour of span entry k among valid entries [lo, hi) within +-8, key {area bits, position}
@@ -69,8 +90,8 @@ __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
 }
 
 // counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
-__global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const u32* __restrict__ ids_in, u32* __restrict__ ids_out,
-                                                        bvh2_node* __restrict__ nodes, const bvh_primref* __restrict__ leaves,
+__global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
+                                                        bvh2_node* __restrict__ nodes,
                                                         u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni) {
     __shared__ PlocLds s;
     const u32 C = counts[0];
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const u32* __restrict__ 
     if (C < (u32)PLOC_CHUNK) {
         // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
         if (blockIdx.x != 0) return;
-        for (int k = tid; k < (int)C; k += PL_BLOCK) { const u32 id = ids_in[k]; lds_set(s, k, id, cluster_box(id, ni, leaves, nodes)); }
+        for (int k = tid; k < (int)C; k += PL_BLOCK) { u32 id; Box b; entry_load(list_in, (size_t)k, id, b); lds_set(s, k, id, b); }
         __syncthreads();
         u32 c = C;
         while (c > 1) {
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const u32* __restrict__ 
         // span entry k <-> list position o - HALO + k   (:232-249)
         for (int k = tid; k < PL_SPAN; k += PL_BLOCK) {
             const long long gpos = o - PL_HALO + k;
-            if (gpos >= 0 && gpos < (long long)C) { const u32 id = ids_in[gpos]; lds_set(s, k, id, cluster_box(id, ni, leaves, nodes)); }
+            if (gpos >= 0 && gpos < (long long)C) { u32 id; Box b; entry_load(list_in, (size_t)gpos, id, b); lds_set(s, k, id, b); }
             else s.id[k] = INV;
         }
         __syncthreads();
@@ -156,32 +177,45 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const u32* __restrict__ 
                 const u32 nb = s.nn[k];
                 const bool mutual = s.nn[nb] == (u32)k;                                              // :276-287
                 mrg[q] = mutual && (u32)k < nb; keep[q] = !mutual || mrg[q];
-                cid[q] = s.id[k];
-                if (mrg[q]) { pid[q] = s.id[nb]; cb[q] = box_union(lds_box(s, k), lds_box(s, (int)nb)); }
+                cid[q] = s.id[k]; cb[q] = lds_box(s, k);
+                if (mrg[q]) { pid[q] = s.id[nb]; cb[q] = box_union(cb[q], lds_box(s, (int)nb)); }
                 packed += ((u32)mrg[q] << 16) + (u32)keep[q];
             }
         }
         u32 tot; u32 ex = block_scan(s, packed, &tot);
-        // chain the chunk totals: status word {flag:2, merges:31, kept:31}
-        if (tid == 0) {
+        // chain the chunk totals: status word {flag:2, merges:31, kept:31}.  Wave 0 walks back 64 predecessors per step
+        // (one load per lane, ballot for the nearest inclusive prefix, wave reduction of the aggregates in front of it) —
+        // a one-thread walk costs a memory round trip per predecessor, which dominated small scenes.
+        if (tid < WAVE) {
             const u64 mine = ((u64)(tot >> 16) << 31) | (u64)(tot & 0xFFFFu);
             u64 excl = 0;
-            if (chunk == 0) __hip_atomic_store(status + chunk, PS_INCL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (chunk == 0) { if (tid == 0) __hip_atomic_store(status + chunk, PS_INCL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else {
-                __hip_atomic_store(status + chunk, PS_LOCAL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                long long prev = (long long)chunk - 1;
+                if (tid == 0) __hip_atomic_store(status + chunk, PS_LOCAL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long long hi = (long long)chunk - 1;                       // nearest predecessor not yet accounted for
                 while (true) {
-                    const u64 st = __hip_atomic_load(status + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const long long idx = hi - tid;                        // lane 0 looks at the nearest
+                    const u64 st = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PS_INCL;
                     const u64 flag = st >> 62;
-                    if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
-                    excl += st & ((1ull << 62) - 1ull);
-                    if (flag == 2) break;
-                    --prev;
+                    const u64 unpub = __ballot(flag == 0), incl = __ballot(flag == 2);
+                    // usable prefix of the window: lanes below the first unpublished one, up to and including the first inclusive one
+                    const int first_unpub = unpub ? __ffsll((unsigned long long)unpub) - 1 : WAVE;
+                    const int first_incl = incl ? __ffsll((unsigned long long)incl) - 1 : WAVE;
+                    const int take = first_incl < first_unpub ? first_incl + 1 : first_unpub;      // lanes [0, take)
+                    u64 v = (tid < take) ? (st & ((1ull << 62) - 1ull)) : 0ull;
+#pragma unroll
+                    for (int m = 1; m < WAVE; m <<= 1) v += __shfl_xor(v, m);
+                    excl += v;
+                    if (first_incl < first_unpub) break;
+                    hi -= take;
+                    if (take == 0) __builtin_amdgcn_s_sleep(1);
                 }
-                __hip_atomic_store(status + chunk, PS_INCL | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) __hip_atomic_store(status + chunk, PS_INCL | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            s.bcast[1] = (u32)(excl >> 31); s.bcast[2] = (u32)(excl & 0x7FFFFFFFull);
-            if (chunk == chunks - 1) { counts[1] = C - ((u32)(excl >> 31) + (tot >> 16)); atomicAdd(iters_done, 1u); }   // src/PLOC++Bvh.cpp:150
+            if (tid == 0) {
+                s.bcast[1] = (u32)(excl >> 31); s.bcast[2] = (u32)(excl & 0x7FFFFFFFull);
+                if (chunk == chunks - 1) { counts[1] = C - ((u32)(excl >> 31) + (tot >> 16)); atomicAdd(iters_done, 1u); }   // src/PLOC++Bvh.cpp:150
+            }
         }
         __syncthreads();
         const u32 m_ex = s.bcast[1], k_ex = s.bcast[2];
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const u32* __restrict__ 
                     bvh2_node* nd = nodes + id;
                     nd->left = cid[q]; nd->right = pid[q]; box_store(&nd->aabb, cb[q]);
                 }
-                ids_out[k_ex + (ex & 0xFFFFu)] = id;                                                 // :355-361
+                entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);                   // :355-361
             }
             ex += ((u32)mrg[q] << 16) + (u32)keep[q];
         }
@@ -205,7 +239,7 @@ __global__ void k_ploc_init(u32* state, u32 n) { if (threadIdx.x == 0) state[0] 
 
 // state words: counts[0..MAX_ITERS] | tickets[0..MAX_ITERS) | iterations done
 void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves) {
-    launch_setup_clusters(s, d_boxes, d_svals, n, d_leaves, sc.ids0, nullptr);
+    { KernelScope ks(s, "k_ploc_setup"); hipLaunchKernelGGL(k_ploc_setup, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves, (float4*)sc.list0, n); }
     ploc_reset(s, sc, n, n);
 }
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count) {
@@ -215,14 +249,15 @@ void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count
 }
 // enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity) {
+    (void)d_leaves;
     const u32 chunks = ploc_chunks(n);
     const u32 grid = chunks < 1024u ? chunks : 1024u;
     u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
     KernelScope ks(s, "k_ploc_iter");                   // the batch of launches is timed as one group
     for (int k = first; k < first + count; ++k) {
         const bool even = ((k + parity) & 1) == 0;
-        hipLaunchKernelGGL(k_ploc_iter, dim3(grid), dim3(PL_BLOCK), 0, s, even ? sc.ids0 : sc.ids1, even ? sc.ids1 : sc.ids0,
-                           (bvh2_node*)d_nodes, (const bvh_primref*)d_leaves, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
+        hipLaunchKernelGGL(k_ploc_iter, dim3(grid), dim3(PL_BLOCK), 0, s, (const float4*)(even ? sc.list0 : sc.list1), (float4*)(even ? sc.list1 : sc.list0),
+                           (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
     }
 }
 

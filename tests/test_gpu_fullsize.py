@@ -1,0 +1,94 @@
+"""GPU, BASELINE.json's full sizes (10 M-triangle uniform mesh; 262 144-triangle Sponza-class mesh): size-independent properties —
+sortedness and permutation of the sort output, structural validity of the tree (every primitive reachable exactly once, every
+internal box = union of its children, bit exact), root box = scene extent, the two HPLOC schedulers agree on the topology, and the
+device-side SAH equals the CPU evaluation of the downloaded tree.  (The oracle itself is run at these sizes only where it finishes
+in seconds: the LBVH emitters.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+N_FULL = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def big(pkg):
+    return pkg.meshgen.uniform(N_FULL, 1)
+
+
+def _check_common(pkg, orc, got, tris, scene):
+    n = len(tris)
+    k = got["sorted_keys"]
+    assert np.all(k[1:] >= k[:-1]), "sorted keys not ascending"
+    assert np.array_equal(np.sort(got["sorted_vals"]), np.arange(n, dtype=np.uint32)), "sorted values are not a permutation"
+    assert got["scene"].tobytes() == scene.tobytes()
+    assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
+    root = got["nodes"][got["root"]]
+    assert np.array_equal(root["min"], scene["min"][0]) and np.array_equal(root["max"], scene["max"][0])
+
+
+def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
+    n = len(big)
+    _, scene = orc.prim_bounds(big)
+    hashes, sahs = [], []
+    for mode in ("levels", "async"):
+        os.environ["BVH_HPLOC_MODE"] = mode
+        try:
+            b = pkg.HPLOC().build(ctx, big)
+            got = b.download()
+        finally:
+            del os.environ["BVH_HPLOC_MODE"]
+        _check_common(pkg, orc, got, big, scene)
+        assert np.array_equal(got["leaves"]["prim"], got["sorted_vals"])
+        hashes.append(orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1))
+        s_cpu = orc.sah_bvh2(got["nodes"], got["leaves"], 0, n, 1)[0]
+        assert abs(b.sah_cost() - s_cpu) <= 1e-9 * s_cpu
+        sahs.append(s_cpu)
+    assert hashes[0] == hashes[1], "level-synchronous and asynchronous HPLOC schedulers must build the same tree"
+
+
+@pytest.mark.parametrize("algo", [1, 0])
+def test_lbvh_10m_bit_exact(pkg, orc, ctx, big, algo):
+    """the LBVH oracle is linear-time: bit-exact comparison at full size"""
+    n = len(big)
+    b = pkg.BUILDERS[algo]().build(ctx, big)
+    got = b.download()
+    boxes, scene = orc.prim_bounds(big)
+    _check_common(pkg, orc, got, big, scene)
+    keys, vals = orc.morton_codes(boxes, scene)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(got["sorted_keys"], keys[order]) and np.array_equal(got["sorted_vals"], order.astype(np.uint32))
+    if algo == 1:
+        ref, root = orc.lbvh_single(big, got["sorted_keys"], got["sorted_vals"])
+        assert root == got["root"]
+    else:
+        ref, _ = orc.lbvh_two(big, got["sorted_keys"], got["sorted_vals"])
+    assert got["nodes"].tobytes() == ref.tobytes()
+
+
+def test_ploc_10m_properties(pkg, orc, ctx, big):
+    n = len(big)
+    _, scene = orc.prim_bounds(big)
+    b = pkg.PLOCNew().build(ctx, big)
+    got = b.download()
+    _check_common(pkg, orc, got, big, scene)
+    s_cpu = orc.sah_bvh2(got["nodes"], got["leaves"], 0, n, 1)[0]
+    assert abs(b.sah_cost() - s_cpu) <= 1e-9 * s_cpu
+
+
+def test_sponza_262k_all_builders_vs_oracle(pkg, orc, ctx):
+    """BASELINE.json configs[1] / configs[3] size: full oracle comparison (the oracle takes ~1 s here)"""
+    tris = pkg.meshgen.sponza_like(262_144, 3); n = len(tris)
+    for algo in (0, 1, 2, 3):
+        b = pkg.BUILDERS[algo]().build(ctx, tris); got = b.download(); ref = orc.build_tree(algo, tris)
+        if algo in (0, 1, 2):
+            assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["root"] == ref["root"]
+        else:
+            assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1)
+        s_ref = orc.sah_bvh2(ref["nodes"], ref["leaves"], ref["root"], n, ref["layout"])[0]
+        assert abs(b.sah_cost() - s_ref) <= 1e-4 * s_ref
+    # PLOC variants must not be worse than LBVH on their own metric (config 4: "SAH <= reference")
+    sah = {a: pkg.BUILDERS[a]().build(ctx, tris).sah_cost() for a in (1, 2, 3)}
+    assert sah[2] < sah[1] and sah[3] < sah[1]
