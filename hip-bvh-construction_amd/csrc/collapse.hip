@@ -34,7 +34,7 @@ __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __
     const u32 begin = state[1 + level], end = state[1 + level + 1];
     const u32 ni = n - 1;
     __shared__ u32 s_base, s_count;
-    auto box_of = [&](u32 c) -> Box { return (layout == 1 && c >= ni) ? box_load(&leaves[c - ni].aabb) : box_load(&nodes[c].aabb); };
+    auto box_of = [&](u32 c) -> Box { return (layout == 1 && c >= ni) ? box_load_u(&leaves[c - ni].aabb) : box_load(&nodes[c].aabb); };
     for (u32 g0 = begin + blockIdx.x * CL_BLOCK; g0 < end; g0 += gridDim.x * CL_BLOCK) {     // block-uniform
         const u32 g = g0 + threadIdx.x;
         const bool have = g < end;

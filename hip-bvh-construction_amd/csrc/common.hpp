@@ -54,13 +54,21 @@ __device__ __forceinline__ Box node_box_agent(const bvh2_node* n) {
     const u64 a = ld_agent(q + 1), b = ld_agent(q + 2), c = ld_agent(q + 3);
     return { lo_f(a), hi_f(a), lo_f(b), hi_f(b), lo_f(c), hi_f(c) };
 }
-__device__ __forceinline__ Box box_load(const bvh_aabb* p) {   // plain load (data from an earlier kernel)
+// plain loads / stores (data from an earlier kernel).  Aabb arrays (24-byte stride) and Bvh2Node::aabb (offset 8 of 32) are
+// 8-byte aligned: three 8-byte accesses instead of six 4-byte ones.  PrimRef::aabb sits at offset 4 of a 28-byte record:
+// box_load_u for those.
+__device__ __forceinline__ Box box_load(const bvh_aabb* p) {
+    const float2* f = reinterpret_cast<const float2*>(p);
+    const float2 a = f[0], b = f[1], c = f[2];
+    return { a.x, a.y, b.x, b.y, c.x, c.y };
+}
+__device__ __forceinline__ Box box_load_u(const bvh_aabb* p) {
     const float* f = reinterpret_cast<const float*>(p);
     return { f[0], f[1], f[2], f[3], f[4], f[5] };
 }
 __device__ __forceinline__ void box_store(bvh_aabb* p, const Box& b) {
-    float* f = reinterpret_cast<float*>(p);
-    f[0] = b.lx; f[1] = b.ly; f[2] = b.lz; f[3] = b.hx; f[4] = b.hy; f[5] = b.hz;
+    float2* f = reinterpret_cast<float2*>(p);
+    f[0] = make_float2(b.lx, b.ly); f[1] = make_float2(b.lz, b.hx); f[2] = make_float2(b.hy, b.hz);
 }
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

@@ -35,6 +35,15 @@
 
 namespace bvh {
 
+// ablation switch for measurements only (results are wrong when set): compiled in with -DBVH_ABLATION
+static inline int hploc_ablation() {
+#ifdef BVH_ABLATION
+    const char* e = getenv("BVH_HPLOC_DEBUG"); return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
+
 constexpr int HP_BLOCK = 256;
 constexpr u32 HP_HALF = 16;        // WarpSize/2 of the reference's wave32 (src/HplocKernel.h:195,238)
 constexpr int HP_RADIUS = 8;       // PlocRadius, src/Common.h:595
@@ -401,7 +410,7 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, c
     hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
     const u32 gaps = n - 1;
     { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
-                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, n, getenv("BVH_HPLOC_DEBUG") ? atoi(getenv("BVH_HPLOC_DEBUG")) : 0); }
+                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, n, hploc_ablation()); }
 }
 
 // Level-synchronous HPLOC for large n.  level_keys / task_keys / task_ids: u32[n] scratch; sc: the sort's scratch (re-armed here).

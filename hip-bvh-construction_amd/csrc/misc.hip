@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_to_lbvh_layout(const bvh2_node* __restr
     if (g < n) {
         bvh2_node* o = out + ni + g;
         o->left = leaves[g].prim_idx; o->right = INV;
-        box_store(&o->aabb, box_load(&leaves[g].aabb));
+        box_store(&o->aabb, box_load_u(&leaves[g].aabb));
     }
 }
 
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_sah(const bvh2_node* __restrict__ nodes
                                              u32 root, u32 n, int layout, double* __restrict__ out) {
     const u32 ni = n - 1;
     auto area_of = [&](u32 c) -> float {
-        return (layout == 1 && c >= ni) ? box_area(box_load(&leaves[c - ni].aabb)) : box_area(box_load(&nodes[c].aabb));
+        return (layout == 1 && c >= ni) ? box_area(box_load_u(&leaves[c - ni].aabb)) : box_area(box_load(&nodes[c].aabb));
     };
     const double ra = (double)area_of(root);
     double acc = 0.0;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_sah(const bvh2_node* __restrict__ nodes
             if (l != INV) acc += (double)area_of(l) / ra;
             if (r != INV) acc += (double)area_of(r) / ra;
         }
-        if (layout == 1) acc += (double)box_area(box_load(&leaves[g].aabb)) / ra;
+        if (layout == 1) acc += (double)box_area(box_load_u(&leaves[g].aabb)) / ra;
         else if (nodes[ni + g].left != INV) acc += (double)box_area(box_load(&nodes[ni + g].aabb)) / ra;
     }
 #pragma unroll

@@ -222,7 +222,11 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
         hipLaunchKernelGGL(k_hist, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
     { KernelScope ks(s, "k_scan_hist"); hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist); }
-    const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;
+    #ifdef BVH_ABLATION
+    const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // measurements only: results are wrong when set
+#else
+    const int dbg = 0;
+#endif
     const u32* kin = keys_in; const u32* vin = vals_in;
     for (int p = 0; p < passes; ++p) {
         const bool first = p == 0, last = p == passes - 1;
