@@ -52,7 +52,7 @@ def main() -> None:
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--algo", default="hploc", choices=["hploc", "ploc", "lbvh_single", "lbvh_two"])
     ap.add_argument("--mesh", default="uniform", choices=["uniform", "bunny", "sponza"])
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="triangles of the mesh the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="triangles of the mesh the CPU baseline is timed on (0 = skip); ~12 s of single-thread work at 5 M")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
 
