@@ -207,3 +207,44 @@ def test_stage_level_emitters(pkg, orc, ctx, cases, name):
     # argument validation (no GPU work): the reference's kernels have no checks; the ABI returns BVH_E_INVALID_ARG
     assert L.bvh_emit_hploc(ctx.handle, None, d_k.ptr, d_v.ptr, n, d_nodes.ptr, d_leaves.ptr) == -10001
     assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_k.ptr, d_v.ptr, 5, 40) == -10001
+
+
+@pytest.mark.parametrize("mode", ["async", "levels"])
+def test_every_small_size(pkg, orc, ctx, mode, monkeypatch):
+    """n = 2..70 and a few sizes around the 16/32/64 thresholds, all four builders, both HPLOC schedulers"""
+    monkeypatch.setenv("BVH_HPLOC_MODE", mode)
+    for n in list(range(2, 71)) + [127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2049]:
+        tris = pkg.meshgen.uniform(n, 1000 + n)
+        for algo in ((0, 1, 2, 3) if mode == "async" else (3,)):
+            got = pkg.BUILDERS[algo]().build(ctx, tris).download(); ref = orc.build_tree(algo, tris)
+            assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0, (n, algo)
+            if algo in (0, 1, 2):
+                assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["root"] == ref["root"], (n, algo)
+            else:
+                assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1), (n, algo)
+
+
+@pytest.mark.parametrize("kind", ["identical", "two_far_clusters", "line", "point_cloud_dups", "huge_and_tiny"])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
+def test_degenerate_distributions(pkg, orc, ctx, kind, algo):
+    mg = pkg.meshgen
+    if kind == "identical":            # every Morton key equal: the hierarchy comes from the position bits only
+        tris = np.repeat(mg.uniform(1, 3), 3000)
+    elif kind == "two_far_clusters":
+        a = mg.uniform(2000, 4); b = mg.uniform(2000, 5, offset=(1.0e6, 0.0, 0.0)); tris = np.concatenate([a, b])
+    elif kind == "line":               # two zero extents: 30-bit 1-D code
+        tris = mg.uniform(3000, 6)
+        for v in ("v1", "v2", "v3"):
+            tris[v][:, 1] = 0.5; tris[v][:, 2] = -2.0
+    elif kind == "point_cloud_dups":   # 64 distinct positions, each 50 times
+        tris = np.tile(mg.uniform(64, 7), 50)
+    else:                              # one scene-sized triangle among tiny ones (Sponza-like size variance)
+        tris = mg.uniform(4000, 8); tris["v1"][0] = (-50, -50, -50); tris["v2"][0] = (60, 0, 0); tris["v3"][0] = (0, 70, 55)
+    tris = np.ascontiguousarray(tris); n = len(tris)
+    got = pkg.BUILDERS[algo]().build(ctx, tris).download(); ref = orc.build_tree(algo, tris)
+    assert np.array_equal(got["sorted_keys"], ref["skeys"]) and np.array_equal(got["sorted_vals"], ref["svals"])
+    assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
+    if algo in (0, 1, 2):
+        assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["root"] == ref["root"]
+    else:
+        assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1)
