@@ -89,9 +89,10 @@ def main() -> None:
         tris = pkg.meshgen.sponza_like(n, seed + 2)
     gen_s = time.time() - t0
 
-    # work is enqueued on torch's current stream so that the RCCL all-gather is ordered after the build
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = pkg.Context(local, stream if stream else None)
+    # builds and the RCCL all-gather share ONE torch side stream (the null stream would not order against the ctx's own stream)
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    ctx = pkg.Context(local, side.cuda_stream)
     d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()      # input resident in HBM before the timed region
     ctx.reserve(n)
     builder = pkg.BUILDERS[algo]()
@@ -134,6 +135,9 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()
+    if world > 1 and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
+        torch.cuda.synchronize()
+        assert torch.equal(gathered[6 * rank: 6 * rank + 6], root_box), "all-gather of root AABBs is inconsistent"
     ctx.set_profiling(1)
     builder.build(ctx, d_tris, on_device=True, n=n)          # one extra build with stage events (reference Timer tokens)
     stage = dict(builder.m_timer)
