@@ -31,7 +31,7 @@ KERNEL_BYTES_PER_PRIM = {
     "k_extents": 88.0,            # R Triangle 64 + W Aabb 24
     "k_morton": 32.0,             # R Aabb 24 + W key 4 + W val 4   (this build: 28, value is implicit)
     "k_onesweep": 17.0,           # per pass: R 8 + W 8 (+ hist R 4 amortised over 4 passes)
-    "k_setup_clusters": 64.0,     # R val 4 + gather Aabb 24 + W PrimRef 28 + W nodeIdx 4 + W parentIdx 4
+    "k_ploc_setup": 88.0,         # SetupClusters for PLOC++: R val 4 + gather Aabb 24 + W PrimRef 28 + W list entry 32
     "k_hploc": 134.0,             # keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32
     "k_hp_level": 114.0,          # level-synchronous variant, all 62 level launches as one group: the same minus keys (4, read by
                                   # k_hp_plan) and the parent exchange (16, replaced by launch order)

@@ -50,7 +50,7 @@ struct bvh_ctx {
     u64* slots = nullptr;             // cap           (single-pass LBVH hand-off words)
     u32* parent = nullptr;            // 2*cap         (two-pass parent pointers / HPLOC parentIdx)
     u32* flags = nullptr;             // cap           (two-pass refit flags)
-    u32* cidx = nullptr;              // cap           (HPLOC nodeIndices0 / PLOC ids0)
+    u32* cidx = nullptr;              // cap           (general u32 scratch: HPLOC level mode sorted level keys)
     PlocScratch ploc{};
     u32* small = nullptr;             // 64 words: [0] root, [1] hploc node counter, [8..9] f64 SAH
     hipEvent_t ev[6] = {};

@@ -48,21 +48,6 @@ constexpr int HP_BLOCK = 256;
 constexpr u32 HP_HALF = 16;        // WarpSize/2 of the reference's wave32 (src/HplocKernel.h:195,238)
 constexpr int HP_RADIUS = 8;       // PlocRadius, src/Common.h:595
 
-// SetupClusters (:39-56) as a stand-alone kernel — used by PLOC++ (ploc.hip); HPLOC fuses it (see above).
-__global__ __launch_bounds__(256) void k_setup_clusters(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals,
-                                                        bvh_primref* __restrict__ leaves, u32* __restrict__ cidx,
-                                                        u32* __restrict__ parent, u32 n) {
-    const u32 g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n) return;
-    const u32 prim = svals[g];
-    const Box b = box_load(boxes + prim);
-    float* f = reinterpret_cast<float*>(leaves + g);
-    reinterpret_cast<u32*>(f)[0] = prim;
-    f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-    cidx[g] = g + (n - 1);
-    if (parent) parent[g] = INV;
-}
-
 __device__ __forceinline__ int clz64(u64 v) { return v ? __clzll((long long)v) : 64; }
 __device__ __forceinline__ float dpp_shl1(float v) {   // lane i <- lane i+1 (whole wave; DPP wave_shl:1)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, true));   // bound_ctrl: lane 63 reads 0
@@ -397,12 +382,6 @@ __global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32
         reduce_and_store<false>(wA, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
         reduce_and_store<false>(wB, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
     }
-}
-
-void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,
-                           uint32_t* d_cluster_idx, uint32_t* d_parent) {
-    { KernelScope ks(s, "k_setup_clusters"); hipLaunchKernelGGL(k_setup_clusters, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_svals,
-                       (bvh_primref*)d_leaves, d_cluster_idx, d_parent, n); }
 }
 
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,

@@ -73,8 +73,6 @@ constexpr int PLOC_CHUNK = 1024;
 constexpr int PLOC_MAX_ITERS = 96;
 constexpr int PLOC_STATE_WORDS = 2 * PLOC_MAX_ITERS + 4;     // counts[MAX+1] | tickets[MAX] | iterations done
 inline uint32_t ploc_chunks(uint32_t n) { return (n + PLOC_CHUNK - 1) / PLOC_CHUNK; }
-void launch_setup_clusters(hipStream_t s, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves,
-                           uint32_t* d_cluster_idx, uint32_t* d_parent /*may be null*/);
 void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves);
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count);
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity);
