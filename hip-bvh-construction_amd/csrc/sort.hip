@@ -98,8 +98,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
             val[i] = IOTA ? (base + local) : (ok ? vals_in[base + local] : 0u);
         }
     }
-    // ---- rank inside the wave: lanes holding the same digit form a group (8 ballots); the group's lowest lane bumps the
-    // wave's LDS counter for that digit, every member gets counter-before + its index inside the group.  Program order
+    // ---- rank inside the wave: lanes holding the same digit form a group (8 ballots); every member reads the wave's LDS
+    // counter for that digit, the group's lowest lane bumps it; rank = counter-before + index inside the group.  Program order
     // (item-major, then lane) is exactly memory order inside the wave's span => stable.
     const u64 lt = lanemask_lt();
 #pragma unroll
@@ -113,10 +113,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
             grp &= bit ? bal : ~bal;
         }
         const u32 below = (u32)__popcll(grp & lt);
-        const int leader = __ffsll((unsigned long long)grp) - 1;
-        u32 before = 0;
-        if (below == 0) { before = s_whist[wave][d]; s_whist[wave][d] = before + (u32)__popcll(grp); }
-        pos[i] = (u32)__shfl((int)before, leader) + below;
+        // every member reads the counter (same address -> LDS broadcast), then the group's lowest lane bumps it; DS
+        // operations of a wave execute in order, so the next item's read sees the update without a cross-lane hop
+        const u32 before = s_whist[wave][d];
+        if (below == 0) s_whist[wave][d] = before + (u32)__popcll(grp);
+        pos[i] = before + below;
     }
     __syncthreads();
 
