@@ -41,18 +41,60 @@ __device__ __forceinline__ u64 pack2(float a, float b) { return (u64)__float_as_
 __device__ __forceinline__ float lo_f(u64 v) { return __uint_as_float((u32)v); }
 __device__ __forceinline__ float hi_f(u64 v) { return __uint_as_float((u32)(v >> 32)); }
 
-// Bvh2Node (32 B, 32-B aligned) = 4 x u64: {left,right} {lx,ly} {lz,hx} {hy,hz}
+// Bvh2Node (32 B, 32-B aligned) written as two 16-byte write-through (sc1) stores: a dwordx2 sc1 store costs ~2.7x a dwordx4
+// one per byte on this chip (MI355X_MICROARCH.md, stores table).  Inline asm: hipcc has no builtin for a 16-byte global store
+// with the sc1 bit; the trailing s_nop keeps the data registers alive until the store has read them (guide §5.7 item 1),
+// completion is awaited by drain_stores() before the publishing atomic, as for every other agent-scope store.
+#ifndef BVH_NODE_STORE_X4
+#define BVH_NODE_STORE_X4 1
+#endif
 __device__ __forceinline__ void node_store_agent(bvh2_node* n, u32 left, u32 right, const Box& b) {
+#if BVH_NODE_STORE_X4
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f q0 = { __uint_as_float(left), __uint_as_float(right), b.lx, b.ly };
+    const v4f q1 = { b.lz, b.hx, b.hy, b.hz };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
+                 :: "v"(n), "v"(q0), "v"(q1) : "memory");
+#else
     u64* q = reinterpret_cast<u64*>(n);
     st_agent(q + 0, (u64)left | ((u64)right << 32));
     st_agent(q + 1, pack2(b.lx, b.ly));
     st_agent(q + 2, pack2(b.lz, b.hx));
     st_agent(q + 3, pack2(b.hy, b.hz));
+#endif
 }
 __device__ __forceinline__ Box node_box_agent(const bvh2_node* n) {
+#if BVH_NODE_STORE_X4
+    // two 16-byte sc1 loads (8-byte agent-scope accesses run at 0.54-0.70x the 16-byte rate); the wait is part of the
+    // statement because hipcc does not count loads issued from inline asm (guide §5.7 item 1, form (i))
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f q0, q1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1) : "v"(n) : "memory");
+    return { q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#else
     const u64* q = reinterpret_cast<const u64*>(n);
     const u64 a = ld_agent(q + 1), b = ld_agent(q + 2), c = ld_agent(q + 3);
     return { lo_f(a), hi_f(a), lo_f(b), hi_f(b), lo_f(c), hi_f(c) };
+#endif
+}
+// box part only (bytes 8..31) of a node whose child links were written earlier: 8-byte + 16-byte write-through stores
+__device__ __forceinline__ void node_box_store_agent(bvh2_node* n, const Box& b) {
+    u64* q = reinterpret_cast<u64*>(n);
+    st_agent(q + 1, pack2(b.lx, b.ly));
+#if BVH_NODE_STORE_X4
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f q1 = { b.lz, b.hx, b.hy, b.hz };
+    asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(n), "v"(q1) : "memory");
+#else
+    st_agent(q + 2, pack2(b.lz, b.hx)); st_agent(q + 3, pack2(b.hy, b.hz));
+#endif
+}
+// whole node, plain (cached) stores: two 16-byte writes
+__device__ __forceinline__ void node_store_plain(bvh2_node* n, u32 left, u32 right, const Box& b) {
+    float4* q = reinterpret_cast<float4*>(n);
+    q[0] = make_float4(__uint_as_float(left), __uint_as_float(right), b.lx, b.ly);
+    q[1] = make_float4(b.lz, b.hx, b.hy, b.hz);
 }
 // plain loads / stores (data from an earlier kernel).  Aabb arrays (24-byte stride) and Bvh2Node::aabb (offset 8 of 32) are
 // 8-byte aligned: three 8-byte accesses instead of six 4-byte ones.  PrimRef::aabb sits at offset 4 of a 28-byte record:

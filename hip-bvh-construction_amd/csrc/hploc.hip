@@ -77,9 +77,7 @@ template <bool AGENT> __device__ __forceinline__ Box node_box(const bvh2_node* n
 }
 template <bool AGENT> __device__ __forceinline__ void node_store(bvh2_node* n, u32 l, u32 r, const Box& b) {
     if (AGENT) { node_store_agent(n, l, r, b); return; }
-    float4* q = reinterpret_cast<float4*>(n);
-    q[0] = make_float4(__uint_as_float(l), __uint_as_float(r), b.lx, b.ly);
-    q[1] = make_float4(b.lz, b.hx, b.hy, b.hz);
+    node_store_plain(n, l, r, b);
 }
 
 struct HpEntry { u32 id, rep, prim; };   // prim: primitive index prefetched for implicit leaves, INV otherwise

@@ -72,9 +72,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
     const u32 ni = n - 1;
     {   // InitBvhNodesPrimRef (:164-194): leaf = {primRef.primIdx, INVALID, primRef.aabb}; PrimRef i = {i, bounds(tri i)}
         const u32 prim = svals[g];
-        bvh2_node* leaf = nodes + ni + g;
-        leaf->left = prim; leaf->right = INV;
-        box_store(&leaf->aabb, box_load(boxes + prim));
+        node_store_plain(nodes + ni + g, prim, INV, box_load(boxes + prim));
     }
     if (g >= ni) return;
     const u32 idx = g;
@@ -121,8 +119,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
         const u32 l = nodes[p].left, r = nodes[p].right;    // links: previous launch
         const u32 sib = (l == cur) ? r : l;
         box = box_union(box, node_box_agent(nodes + sib));
-        u64* q = reinterpret_cast<u64*>(nodes + p);
-        st_agent(q + 1, pack2(box.lx, box.ly)); st_agent(q + 2, pack2(box.lz, box.hx)); st_agent(q + 3, pack2(box.hy, box.hz));
+        node_box_store_agent(nodes + p, box);
         cur = p; p = parent[p];
     }
 }

@@ -131,8 +131,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
                     u32 id = cid[q];
                     if (mrg[q]) {
                         id = c - 2 - (ex >> 16);                  // :168
-                        bvh2_node* nd = nodes + id;
-                        nd->left = cid[q]; nd->right = pid[q]; box_store(&nd->aabb, cb[q]);
+                        node_store_plain(nodes + id, cid[q], pid[q], cb[q]);
                     }
                     lds_set(s, (int)(ex & 0xFFFFu), id, cb[q]);
                 }
@@ -225,8 +224,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
                 u32 id = cid[q];
                 if (mrg[q]) {
                     id = C - 2 - (m_ex + (ex >> 16));                                                // :311
-                    bvh2_node* nd = nodes + id;
-                    nd->left = cid[q]; nd->right = pid[q]; box_store(&nd->aabb, cb[q]);
+                    node_store_plain(nodes + id, cid[q], pid[q], cb[q]);
                 }
                 entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);                   // :355-361
             }
