@@ -59,14 +59,20 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
 // Two pass.  k_karras: node i's range and split from the sorted keys (:42-130), child links + parent pointers, leaf
 // records.  k_refit: bottom-up boxes, second arriver at flags[parent] continues (:217-235).
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int delta2p(const u32* __restrict__ k, u32 i, u32 j) {   // countCommonPrefixBits as used at :52-54
-    const u32 a = k[i], b = k[j];
-    return (a == b) ? (32 + __clz((int)(i ^ j))) : __clz((int)(a ^ b));
-}
-
+// The block's key window [g0 - 256, g0 + 512] is staged in LDS: the exponential / binary searches of determineRange and
+// findSplit probe it instead of paying an L2 round trip per probe; only ranges reaching beyond the window read global memory.
 __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ k,
                                                        const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
                                                        u32* __restrict__ parent, u32 n) {
+    __shared__ u32 s_keys[LBVH_BLOCK * 3 + 1];
+    const int g0 = (int)(blockIdx.x * LBVH_BLOCK), w0 = g0 - LBVH_BLOCK;
+    for (int t = threadIdx.x; t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : 0u; }
+    __syncthreads();
+    auto key_at = [&](u32 j) -> u32 { return ((u32)((int)j - w0) <= (u32)(LBVH_BLOCK * 3)) ? s_keys[(int)j - w0] : k[j]; };
+    auto delta2p = [&](u32 i, u32 j) -> int {                  // countCommonPrefixBits as used at :52-54
+        const u32 a = key_at(i), b = key_at(j);
+        return (a == b) ? (32 + __clz((int)(i ^ j))) : __clz((int)(a ^ b));
+    };
     const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
     if (g >= n) return;
     const u32 ni = n - 1;
@@ -79,10 +85,10 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
     u32 first, last;
     if (idx == 0) { first = 0; last = n - 1; parent[0] = INV; }
     else {
-        const int ld = delta2p(k, idx, idx - 1), rd = delta2p(k, idx, idx + 1);
+        const int ld = delta2p(idx, idx - 1), rd = delta2p(idx, idx + 1);
         const int d = (rd > ld) ? 1 : -1;
         const int dmin = (ld < rd) ? ld : rd;
-        auto probe = [&](long long jj) -> int { return (jj >= 0 && jj < (long long)n) ? delta2p(k, idx, (u32)jj) : -1; };
+        auto probe = [&](long long jj) -> int { return (jj >= 0 && jj < (long long)n) ? delta2p(idx, (u32)jj) : -1; };
         long long lmax = 2;
         while (probe((long long)idx + d * lmax) > dmin) lmax <<= 1;
         long long l = 0;
@@ -91,12 +97,12 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
         const u32 jdx = (u32)((long long)idx + l * d);
         if (d < 0) { first = jdx; last = idx; } else { first = idx; last = jdx; }
     }
-    const u32 dnode = (u32)delta2p(k, first, last);
+    const u32 dnode = (u32)delta2p(first, last);
     int split = (int)first, stride = (int)(last - first);
     do {
         stride = (stride + 1) >> 1;
         const int mid = split + stride;
-        if ((u32)mid < last && (u32)delta2p(k, first, (u32)mid) > dnode) split = mid;
+        if ((u32)mid < last && (u32)delta2p(first, (u32)mid) > dnode) split = mid;
     } while (stride > 1);
     const u32 s = (u32)split;
     const u32 lc = (s == first) ? s + ni : s;                // :210-211
@@ -114,10 +120,11 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
     u32 p = parent[cur];
     while (p != INV) {
         drain_stores();
-        if (__hip_atomic_fetch_add(flags + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+        // the reference counts arrivals (atomicAdd(flags) > 0, :224) and then re-reads the child links to find the sibling;
+        // exchanging the arriving child's index instead hands the sibling to the second arriver directly
+        const u32 sib = __hip_atomic_exchange(flags + p, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sib == INV) break;
         compiler_fence();
-        const u32 l = nodes[p].left, r = nodes[p].right;    // links: previous launch
-        const u32 sib = (l == cur) ? r : l;
         box = box_union(box, node_box_agent(nodes + sib));
         node_box_store_agent(nodes + p, box);
         cur = p; p = parent[p];
@@ -135,7 +142,7 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_sk
 
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent, uint32_t* d_flags) {
-    hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(u32), s);
+    hipMemsetAsync(d_flags, 0xFF, (size_t)n * sizeof(u32), s);
     const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
     { KernelScope ks(s, "k_karras"); hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n); }
     { KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n); }
