@@ -60,11 +60,21 @@ namespace {
 
 // HPLOC: asynchronous single-launch kernel below this size, level-synchronous launches above (62 small launches amortise)
 constexpr uint32_t HPLOC_LEVELS_MIN_N = 4000000;   // measured crossover on MI355X: async 3028 vs levels 2643 Mtris/s at 2 M, 3672 vs 4419 at 10 M
-inline bool use_levels(uint32_t n) {
-    const char* e = getenv("BVH_HPLOC_MODE");          // "async" / "levels" override (A/B measurements)
-    if (e && e[0] == 'a') return false;
-    if (e && e[0] == 'l') return true;
-    return n >= HPLOC_LEVELS_MIN_N;
+enum HplocMode { HP_ASYNC, HP_LEVELS, HP_BLOCK };
+inline HplocMode hploc_mode(uint32_t n) {
+    const char* e = getenv("BVH_HPLOC_MODE");          // "async" / "levels" / "block" override (A/B measurements, tests)
+    if (e && e[0] == 'a') return HP_ASYNC;
+    if (e && e[0] == 'l') return HP_LEVELS;
+    if (e && e[0] == 'b') return n > 2 * hploc_block_tile() ? HP_BLOCK : HP_ASYNC;
+    return n >= HPLOC_LEVELS_MIN_N ? HP_LEVELS : HP_ASYNC;
+}
+// HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
+void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const u32* d_skeys, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves) {
+    switch (hploc_mode(n)) {
+        case HP_LEVELS: launch_hploc_levels(s, c->sort, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, reinterpret_cast<uint4*>(c->sort.pairs0), c->small + 1); break;
+        case HP_BLOCK:  launch_hploc_block(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1, c->cidx, c->small + 2); break;
+        default:        launch_hploc(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1); break;
+    }
 }
 
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
@@ -287,8 +297,7 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    if (use_levels(n)) launch_hploc_levels(c->stream, c->sort, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, reinterpret_cast<uint4*>(c->sort.pairs0), c->small + 1);
-    else launch_hploc(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
+    emit_hploc(c, c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves);
     return herr(hipGetLastError());
 }
 
@@ -325,8 +334,7 @@ int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_
     switch (algo) {
         case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->slots, c->small); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->parent, c->flags); break;
-        case BVH_HPLOC:           if (use_levels(n)) launch_hploc_levels(s, c->sort, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, reinterpret_cast<uint4*>(c->sort.pairs0), c->small + 1);
-                                  else launch_hploc(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1);
+        case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);
                                   r = run_ploc(c, n, c->nodes, c->leaves, c->ploc, &ploc_iters); if (r) return r;

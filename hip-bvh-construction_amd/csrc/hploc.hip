@@ -30,6 +30,7 @@
 // agent-scope write-through stores read back with agent-scope loads; a wave drains its stores (s_waitcnt vmcnt(0)) before
 // the agent-scope atomic on counter[] that publishes a finished range.
 #include <cstdlib>
+#include <cstdio>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -37,11 +38,7 @@ namespace bvh {
 
 // ablation switch for measurements only (results are wrong when set): compiled in with -DBVH_ABLATION
 static inline int hploc_ablation() {
-#ifdef BVH_ABLATION
     const char* e = getenv("BVH_HPLOC_DEBUG"); return e ? atoi(e) : 0;
-#else
-    return 0;
-#endif
 }
 
 constexpr int HP_BLOCK = 256;
@@ -99,7 +96,7 @@ __device__ __forceinline__ HpEntry load_entry(bool have, u32 tL, u32 tR, u32 tP,
 struct HpWork { u32 id, rep, cnt, tL; Box b; bool have, final_; };
 
 // left-pack the loaded entries, fetch their boxes (leaves: fused SetupClusters), return the work list of this half
-template <bool AGENT>
+template <bool AGENT, bool SETUP = true>
 __device__ __forceinline__ HpWork prepare(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
                                           const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, const bvh2_node* nodes,
                                           u32 ni, int slot, int hbase) {
@@ -117,20 +114,21 @@ __device__ __forceinline__ HpWork prepare(bool have, u32 tL, u32 tR, HpEntry en,
             if (id >= ni) {   // first (and only) load of this leaf: fused SetupClusters (:44-47)
                 if (prim == INV) prim = svals[rep];
                 b = box_load(boxes + prim);
-                float* f = reinterpret_cast<float*>(leaves + rep);
-                reinterpret_cast<u32*>(f)[0] = prim;
-                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+                if (SETUP) {  // (SETUP = false: the block-local kernel wrote every PrimRef while staging its leaves)
+                    float* f = reinterpret_cast<float*>(leaves + rep);
+                    reinterpret_cast<u32*>(f)[0] = prim;
+                    f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+                }
             } else b = node_box<AGENT>(nodes + id);                                                  // :242-246
         }
         HpWork w; w.id = id; w.rep = rep; w.cnt = cnt; w.tL = tL; w.b = b; w.have = have; w.final_ = have && tL == 0 && tR == ni;
         return w;
 }
 
-// PLOC rounds until <= 16 clusters (root: 1) remain, then storeIndices
+// PLOC rounds until <= 16 clusters (root: 1) remain; the work list stays in registers (w is updated in place)
 template <bool AGENT>
-__device__ __forceinline__ void reduce_and_store(HpWork w, bvh2_node* nodes, u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
+__device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
         const bool have = w.have, final_ = w.final_;
-        const u32 tL = w.tL;
         u32 id = w.id, rep = w.rep, cnt = w.cnt;
         Box b = w.b;
         const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
@@ -193,15 +191,64 @@ __device__ __forceinline__ void reduce_and_store(HpWork w, bvh2_node* nodes, u64
             b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
             if (act) { if ((u32)slot >= newcnt) id = INV; cnt = newcnt; }
         }
-        // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
-        if (have && !final_ && slot < 16) st_e<AGENT>(cidx + tL + slot, entry(id, rep));
+        w.id = id; w.rep = rep; w.cnt = cnt; w.b = b;
 }
 
+// PLOC rounds, then storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
 template <bool AGENT>
+__device__ __forceinline__ void reduce_and_store(HpWork w, bvh2_node* nodes, u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
+        ploc_rounds<AGENT>(w, nodes, zero_parent, ni, lane, slot, hbase, dbg);
+        if (w.have && !w.final_ && slot < 16) st_e<AGENT>(cidx + w.tL + slot, entry(w.id, w.rep));
+}
+
+template <bool AGENT, bool SETUP = true>
 __device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
                                            const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
                                            u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
-    reduce_and_store<AGENT>(prepare<AGENT>(have, tL, tR, en, boxes, svals, leaves, nodes, ni, slot, hbase), nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
+    reduce_and_store<AGENT>(prepare<AGENT, SETUP>(have, tL, tR, en, boxes, svals, leaves, nodes, ni, slot, hbase), nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
+}
+
+// ---- the asynchronous part: run ready merge tasks, two per pass (one per 32-lane half of the wave), then hand the finished
+// range to the parent node; whoever completes the parent's dependency count (3) runs it next.  No waiting anywhere.
+// PROP = true: a node's range is assembled bottom-up — the finishing left child stores its L into the low half of ranges[q], the
+// right child its R into the high half (the parent's own thread supplies the half of a small child), so nobody searches.
+template <bool SETUP, bool PROP = false>
+__device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+                                            const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes, u64* cidx,
+                                            u64* ranges, u32* counter, u32* zero_parent, u32 ni, int lane, int dbg) {
+    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
+    while (true) {
+        const u64 rm = __ballot(ready);
+        if (!rm) break;
+        const int ownA = __ffsll((unsigned long long)rm) - 1;
+        const u64 rm2 = rm & (rm - 1);
+        const int ownB = rm2 ? __ffsll((unsigned long long)rm2) - 1 : -1;
+        const int own = half ? ownB : ownA;
+        const bool have = own >= 0;
+        const int osrc = have ? own : 0;
+        const u32 tL = (u32)__shfl((int)L, osrc), tR = (u32)__shfl((int)R, osrc), tP = (u32)__shfl((int)pc, osrc);
+        merge_exec<true, SETUP>(have, tL, tR, load_entry<true>(have, tL, tR, tP, svals, cidx, ni, slot), boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
+
+        // -- the owners hand their finished range to the parent node
+        if (ready && (lane == ownA || lane == ownB)) {
+            ready = false;
+            if (!(L == 0 && R == ni)) {
+                // findParent (:66-81): the boundary gap with the longer common prefix (smaller xor) is the parent
+                u32 q;
+                if (L == 0) q = R;
+                else if (R == ni) q = L - 1;
+                else q = ((aug_key(skeys, R) ^ aug_key(skeys, R + 1)) < (aug_key(skeys, L - 1) ^ aug_key(skeys, L))) ? R : L - 1;
+                if (PROP) st_agent(reinterpret_cast<u32*>(ranges + q) + (q == R ? 0 : 1), q == R ? L : R);
+                drain_stores();                 // the wave's node / survivor stores are in memory before the count moves
+                const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1u == 3u) {
+                    compiler_fence();
+                    const u64 rg = ld_agent(ranges + q);
+                    pc = q; L = (u32)rg; R = (u32)(rg >> 32); ready = true;
+                }
+            }
+        }
+    }
 }
 
 #ifndef HP_WAVES
@@ -211,7 +258,6 @@ __global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __
                                                     const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
                                                     bvh2_node* nodes, u64* cidx, u64* ranges, u32* counter, u32* zero_parent, u32 n, int dbg) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
     const u32 ni = n - 1;
     u32 pc = blockIdx.x * HP_BLOCK + threadIdx.x;      // LBVH gap / node this lane currently speaks for
     u32 L = 0, R = 0;
@@ -262,38 +308,7 @@ __global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __
     }
 
     if (dbg == 1) return;
-    // ---- phase 2: run ready merge tasks, two per pass (one per 32-lane half), then climb ----------------------------------
-    while (true) {
-        const u64 rm = __ballot(ready);
-        if (!rm) break;
-        const int ownA = __ffsll((unsigned long long)rm) - 1;
-        const u64 rm2 = rm & (rm - 1);
-        const int ownB = rm2 ? __ffsll((unsigned long long)rm2) - 1 : -1;
-        const int own = half ? ownB : ownA;
-        const bool have = own >= 0;
-        const int osrc = have ? own : 0;
-        const u32 tL = (u32)__shfl((int)L, osrc), tR = (u32)__shfl((int)R, osrc), tP = (u32)__shfl((int)pc, osrc);
-        merge_exec<true>(have, tL, tR, load_entry<true>(have, tL, tR, tP, svals, cidx, ni, slot), boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
-
-        // -- the owners hand their finished range to the parent node
-        if (ready && (lane == ownA || lane == ownB)) {
-            ready = false;
-            if (!(L == 0 && R == ni)) {
-                // findParent (:66-81): the boundary gap with the longer common prefix (smaller xor) is the parent
-                u32 q;
-                if (L == 0) q = R;
-                else if (R == ni) q = L - 1;
-                else q = ((aug_key(skeys, R) ^ aug_key(skeys, R + 1)) < (aug_key(skeys, L - 1) ^ aug_key(skeys, L))) ? R : L - 1;
-                drain_stores();                 // the wave's node / survivor stores are in memory before the count moves
-                const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + 1u == 3u) {
-                    compiler_fence();
-                    const u64 rg = ld_agent(ranges + q);
-                    pc = q; L = (u32)rg; R = (u32)(rg >> 32); ready = true;
-                }
-            }
-        }
-    }
+    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, cidx, ranges, counter, zero_parent, ni, lane, dbg);
 }
 
 // =====================================================================================================================
@@ -382,12 +397,274 @@ __global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32
     }
 }
 
+// =====================================================================================================================
+// Block-local variant (large inputs).
+//
+// A workgroup owns T consecutive sorted leaves.  Every LBVH node whose leaf range lies inside those T leaves ("local";
+// > 90 % of the merge tasks) is processed from LDS: the block stages its leaves' boxes once (all gathers in flight together —
+// this is also SetupClusters), keeps the work lists of its ranges ({id, rep, box} per surviving cluster, at the range's first
+// 16 positions exactly like the reference's nodeIdx array) in LDS, and walks its local hierarchy level by level (level =
+// 63 - common prefix; a parent's prefix is strictly shorter than its children's) with one barrier per non-empty level.  A
+// local task therefore has no global load in front of its PLOC rounds and only the 32-byte node store behind them.
+// Nodes whose range crosses a block boundary ("external": the ancestors of the T-aligned gaps) run afterwards under the
+// asynchronous dependency protocol of k_hploc (async_climb): the block publishes the survivors of its maximal local ranges
+// to global memory and moves the parents' counters.  One launch, no per-level kernel boundaries, no plan/sort passes.
+// =====================================================================================================================
+template <int T, int NT>
+__global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+                                                    const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
+                                                    bvh2_node* nodes, u64* cidx, u64* ranges, u32* counter, u32* zero_parent,
+                                                    u32* queue, u32* queue_count, u32 n, int dbg) {
+    constexpr int PER = T / NT;                      // leaf positions (and gaps) per thread
+    constexpr int NW = NT / WAVE;
+    static_assert(T % NT == 0 && T <= 32768, "block-local HPLOC tile");
+    __shared__ u32 s_key[T + 2];                     // sorted keys of positions g0-1 .. g0+T
+    __shared__ u32 e_id[T], e_rep[T];                // work lists: cluster id / rep per position   (later: ready list)
+    __shared__ float e_b[6][T];                      //             cluster box (SoA)
+    __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node
+    __shared__ unsigned char m_ext[T];               // per gap: range leaves the block
+    __shared__ unsigned short s_task[T];             // local big nodes grouped by level
+    __shared__ u32 s_cnt[64], s_off[64];
+    __shared__ u32 s_nready;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
+    const u32 ni = n - 1;
+    const u32 g0 = blockIdx.x * (u32)T;
+    const u32 nleaf = (n - g0) < (u32)T ? (n - g0) : (u32)T;
+
+    // ---- stage the block: leaves (SetupClusters :44-47, fused), keys -------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const u32 k = (u32)tid + (u32)i * NT;
+        if (k < nleaf) {
+            const u32 g = g0 + k, prim = svals[g];
+            const Box b = box_load(boxes + prim);
+            float* f = reinterpret_cast<float*>(leaves + g);
+            reinterpret_cast<u32*>(f)[0] = prim;
+            f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+            e_id[k] = ni + g; e_rep[k] = g;
+            e_b[0][k] = b.lx; e_b[1][k] = b.ly; e_b[2][k] = b.lz; e_b[3][k] = b.hx; e_b[4][k] = b.hy; e_b[5][k] = b.hz;
+        }
+    }
+    for (int k = tid; k < T + 2; k += NT) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : 0u; }
+    if (tid < 64) s_cnt[tid] = 0u;
+    if (tid == 0) s_nready = 0u;
+    __syncthreads();
+    if (dbg == 1) return;
+
+    // ---- ranges of the block's gaps, clamped to the window [g0-1, g0+T]; a range touching the window's rim is external
+    const int jmin = g0 ? (int)g0 - 1 : 0;
+    const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
+    auto wkey = [&](int j) -> u64 { return ((u64)s_key[j - (int)g0 + 1] << 32) | (u32)j; };
+    int my_lv[PER]; u32 my_pos[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const u32 k = (u32)tid + (u32)i * NT;
+        const u32 pc = g0 + k;
+        my_lv[i] = -1; my_pos[i] = 0;
+        if (k < nleaf && pc < ni) {
+            const int p = (int)pc;
+            const u64 kp = wkey(p);
+            const int c0 = clz64(kp ^ wkey(p + 1));
+            auto inside = [&](int j) -> bool { return j >= jmin && j <= jmax && clz64(wkey(j) ^ kp) >= c0; };
+            int step = 1;
+            while (inside(p - step)) step <<= 1;
+            int lo = p - (step >> 1);
+            for (int t = step >> 2; t > 0; t >>= 1) if (inside(lo - t)) lo -= t;
+            step = 1;
+            while (inside(p + 1 + step)) step <<= 1;
+            int hi = p + 1 + (step >> 1);
+            for (int t = step >> 2; t > 0; t >>= 1) if (inside(hi + t)) hi += t;
+            const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
+            m_ext[k] = ext ? 1 : 0;
+            if (!ext && (u32)(hi - lo + 1) > HP_HALF) {
+                m_range[k] = (u32)(lo - (int)g0) | ((u32)(hi - (int)g0) << 16);
+                my_lv[i] = 63 - c0;
+                my_pos[i] = atomicAdd(&s_cnt[my_lv[i]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                  // exclusive scan of the level counts
+        const u32 v = s_cnt[tid]; u32 incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
+        s_off[tid] = incl - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)((u32)tid + (u32)i * NT);
+    __syncthreads();
+
+    if (dbg == 2) return;
+    // ---- local hierarchy, deepest level first; two tasks per wave pass ----------------------------------------------------
+    for (int lv = 0; lv < 62; ++lv) {
+        const u32 c = s_cnt[lv];
+        if (!c) continue;                            // block-uniform
+        const u32 base = s_off[lv];
+        for (u32 tw = (u32)wave * 2u; tw < c; tw += (u32)NW * 2u) {
+            const u32 t = tw + (u32)half;
+            const bool have = t < c;
+            u32 P = 0, L = 0, R = 0;
+            if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0xFFFFu; R = rg >> 16; }
+            // loadIndices (:192-206) from the LDS work lists: the first <= 16 valid entries of each child range
+            const bool is_left = slot < 16;
+            const u32 kk = (u32)(slot & 15);
+            const u32 c_start = is_left ? L : P + 1u, c_len = is_left ? (P - L + 1u) : (R - P);
+            u32 idv = INV;
+            if (have && kk < c_len) idv = e_id[c_start + kk];
+            const u32 vb = (u32)(__ballot(idv != INV) >> hbase);
+            const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb >> 16);
+            HpWork w; w.have = have; w.final_ = false; w.tL = g0 + L; w.cnt = nl + nr;
+            w.id = INV; w.rep = INV; w.b = box_empty();
+            if (have && (u32)slot < w.cnt) {
+                const u32 sp = (u32)slot < nl ? L + (u32)slot : P + 1u + ((u32)slot - nl);
+                w.id = e_id[sp]; w.rep = e_rep[sp];
+                w.b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
+            }
+            ploc_rounds<true>(w, nodes, zero_parent, ni, lane, slot, hbase, 0);
+            if (have && slot < 16) {                 // storeIndices (:208-218) into the range's first 16 positions
+                const u32 d = L + (u32)slot;
+                e_id[d] = w.id; e_rep[d] = w.rep;
+                e_b[0][d] = w.b.lx; e_b[1][d] = w.b.ly; e_b[2][d] = w.b.lz; e_b[3][d] = w.b.hx; e_b[4][d] = w.b.hy; e_b[5][d] = w.b.hz;
+            }
+        }
+        __syncthreads();
+    }
+    drain_stores();                                  // every wave's node stores are in memory before the block publishes
+    __syncthreads();
+    if (dbg == 3) return;
+
+    // ---- hand-over: survivors of the maximal local ranges go to global memory and move their (external) parent's count; the
+    // block's external nodes contribute what their own thread knows (which children are small, and those children's far ends).
+    // Nodes whose count completes here are queued for k_hploc_ext.
+    auto gkey = [&](int j) -> u64 {
+        const u32 kv = (j >= jmin && j <= jmax) ? s_key[j - (int)g0 + 1] : skeys[j];
+        return ((u64)kv << 32) | (u32)j;
+    };
+    bool ev[PER]; u32 ev_pc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const u32 k = (u32)tid + (u32)i * NT;
+        const u32 pc = g0 + k;
+        ev[i] = false; ev_pc[i] = 0;
+        if (k < nleaf && pc < ni) {
+            u32* rq = reinterpret_cast<u32*>(ranges + pc);
+            if (m_ext[k]) {
+                const int p = (int)pc;
+                const u64 kp = gkey(p);
+                const int c0 = clz64(kp ^ gkey(p + 1));
+                auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(gkey(j) ^ kp) >= c0; };
+                // child [L, p] is big iff leaf p-16 is inside; child [p+1, R] is big iff leaf p+17 is inside
+                const bool lbig = inside(p - (int)HP_HALF), rbig = inside(p + 1 + (int)HP_HALF);
+                int lo = p, hi = p + 1;
+                if (!lbig) { for (int t = 8; t > 0; t >>= 1) if (inside(lo - t)) lo -= t; }          // L in [p-15, p]
+                if (!rbig) { for (int t = 8; t > 0; t >>= 1) if (inside(hi + t)) hi += t; }          // R in [p+1, p+16]
+                const u32 e = (lbig ? 1u : 0u) + (rbig ? 1u : 0u);
+                if (e == 0u) {
+                    if ((u32)(hi - lo + 1) > HP_HALF) { rq[0] = (u32)lo; rq[1] = (u32)hi; ev[i] = true; ev_pc[i] = pc; }   // read by the next launch
+                } else {
+                    if (!lbig) st_agent(rq + 0, (u32)lo);
+                    if (!rbig) st_agent(rq + 1, (u32)hi);
+                    drain_stores();
+                    const u32 old = __hip_atomic_fetch_add(counter + pc, 3u - e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((old + (3u - e)) == 3u) { ev[i] = true; ev_pc[i] = pc; }
+                }
+            } else if (my_lv[i] >= 0) {
+                const u32 rg = m_range[k];
+                const u32 Lr = rg & 0xFFFFu, L = g0 + Lr, R = g0 + (rg >> 16);
+                u32 q;                                                               // findParent (:66-81)
+                if (L == 0u) q = R;
+                else if (R == ni) q = L - 1u;
+                else q = ((wkey((int)R) ^ wkey((int)R + 1)) < (wkey((int)L - 1) ^ wkey((int)L))) ? R : L - 1u;
+                if (q < g0 || m_ext[q - g0]) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; ++sidx) st_agent(cidx + L + sidx, entry(e_id[Lr + sidx], e_rep[Lr + sidx]));
+                    st_agent(reinterpret_cast<u32*>(ranges + q) + (q == R ? 0 : 1), q == R ? L : R);
+                    drain_stores();
+                    const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old + 1u == 3u) { ev[i] = true; ev_pc[i] = q; }
+                }
+            }
+        }
+    }
+    __syncthreads();                                 // the work lists are dead: their LDS becomes the block's ready list
+    u32* r_pc = e_id;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) if (ev[i]) r_pc[atomicAdd(&s_nready, 1u)] = ev_pc[i];
+    __syncthreads();
+    const u32 nready = s_nready;                     // <= T (one event per gap at most)
+    if (dbg == 4) return;
+    if (nready) {
+        if (tid == 0) s_off[0] = atomicAdd(queue_count, nready);
+        __syncthreads();
+        const u32 at = s_off[0];
+        for (u32 i = (u32)tid; i < nready; i += (u32)NT) queue[at + i] = r_pc[i];
+    }
+}
+
+// External nodes (ranges crossing the tiles of k_hploc_block): the queue holds the nodes whose dependencies were complete when
+// the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
+__global__ __launch_bounds__(256) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+                                                   const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
+                                                   u64* cidx, u64* ranges, u32* counter, u32* zero_parent,
+                                                   const u32* __restrict__ queue, const u32* __restrict__ queue_count, u32 n) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const u32 total = *queue_count;
+    const u32 nwaves = gridDim.x * (256 / WAVE);
+    const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    for (u32 base = wid * 2u; base < total; base += nwaves * 2u) {      // wave-uniform
+        const u32 idx = base + (u32)(lane >> 5);
+        const bool ready = (lane & 31) == 0 && idx < total;
+        u32 pc = 0, L = 0, R = 0;
+        if (ready) { pc = queue[idx]; const u64 rg = ranges[pc]; L = (u32)rg; R = (u32)(rg >> 32); }
+        async_climb<false, true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, cidx, ranges, counter, zero_parent, n - 1, lane, 0);
+    }
+}
+
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent) {
     hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
     const u32 gaps = n - 1;
     { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, n, hploc_ablation()); }
+}
+
+// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  queue: u32[n] scratch; queue_count: one word.
+#ifndef HPB_T
+#define HPB_T 1024
+#endif
+#ifndef HPB_NT
+#define HPB_NT 512
+#endif
+static void hpb_config(int* t, int* nt) {
+    *t = HPB_T; *nt = HPB_NT;
+    const char* e = getenv("BVH_HPB");                 // "T,NT" (measurements only)
+    if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) { *t = a; *nt = b; } }
+}
+uint32_t hploc_block_tile() { int t, nt; hpb_config(&t, &nt); return (uint32_t)t; }
+void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                        void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent,
+                        uint32_t* d_queue, uint32_t* d_queue_count) {
+    (void)hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
+    (void)hipMemsetAsync(d_queue_count, 0, sizeof(u32), s);
+    int t, nt; hpb_config(&t, &nt);
+    const int dbg = hploc_ablation();
+#define HPB_LAUNCH(TT, NN) hipLaunchKernelGGL((k_hploc_block<TT, NN>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, \
+                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, d_queue, d_queue_count, n, dbg)
+    { KernelScope ks(s, "k_hploc_block");
+      if (t == 1024 && nt == 512) HPB_LAUNCH(1024, 512);
+      else if (t == 1024 && nt == 256) HPB_LAUNCH(1024, 256);
+      else if (t == 2048 && nt == 512) HPB_LAUNCH(2048, 512);
+      else if (t == 2048 && nt == 1024) HPB_LAUNCH(2048, 1024);
+      else if (t == 512 && nt == 256) HPB_LAUNCH(512, 256);
+      else HPB_LAUNCH(HPB_T, HPB_NT); }
+#undef HPB_LAUNCH
+    if (dbg) return;
+    KernelScope ks(s, "k_hploc_ext");
+    hipLaunchKernelGGL(k_hploc_ext, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
+                       d_cluster_idx, d_ranges, d_counter, d_zero_parent, (const u32*)d_queue, (const u32*)d_queue_count, n);
 }
 
 // Level-synchronous HPLOC for large n.  level_keys / task_keys / task_ids: u32[n] scratch; sc: the sort's scratch (re-armed here).

@@ -59,6 +59,10 @@ void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx /*u64[n] {id,rep}*/, uint64_t* d_ranges /*u64[n]*/,
                   uint32_t* d_counter /*u32[n]*/, uint32_t* d_zero_parent /*u32[1]*/);
+uint32_t hploc_block_tile();
+void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                        void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent,
+                        uint32_t* d_queue /*u32[n]*/, uint32_t* d_queue_count /*u32[1]*/);
 void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                          void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
                          uint32_t* d_task_keys, uint32_t* d_task_ids, uint4* d_tasks /*uint4[n/17+1]*/, uint32_t* d_zero_parent);
