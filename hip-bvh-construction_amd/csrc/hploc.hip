@@ -410,8 +410,8 @@ __global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32
 // asynchronous dependency protocol of k_hploc (async_climb): the block publishes the survivors of its maximal local ranges
 // to global memory and moves the parents' counters.  One launch, no per-level kernel boundaries, no plan/sort passes.
 // =====================================================================================================================
-template <int T, int NT>
-__global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+template <int T, int NT, int OCC>
+__global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
                                                     bvh2_node* nodes, u64* cidx, u64* ranges, u32* counter, u32* zero_parent,
                                                     u32* queue, u32* queue_count, u32 n, int dbg) {
@@ -419,10 +419,11 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
     constexpr int NW = NT / WAVE;
     static_assert(T % NT == 0 && T <= 32768, "block-local HPLOC tile");
     __shared__ u32 s_key[T + 2];                     // sorted keys of positions g0-1 .. g0+T
-    __shared__ u32 e_id[T], e_rep[T];                // work lists: cluster id / rep per position   (later: ready list)
-    __shared__ float e_b[6][T];                      //             cluster box (SoA)
-    __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node
-    __shared__ unsigned char m_ext[T];               // per gap: range leaves the block
+    // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
+    // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
+    __shared__ unsigned short e_id[T], e_rep[T];     // id: 0x8000 | k = leaf ni + g0 + k;  k = node g0 + k;  0xFFFF = invalid
+    __shared__ float e_b[6][T];                      // (later: the block's ready list)
+    __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level
     __shared__ u32 s_cnt[64], s_off[64];
     __shared__ u32 s_nready;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
             float* f = reinterpret_cast<float*>(leaves + g);
             reinterpret_cast<u32*>(f)[0] = prim;
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-            e_id[k] = ni + g; e_rep[k] = g;
+            e_id[k] = (unsigned short)(0x8000u | k); e_rep[k] = (unsigned short)k;
             e_b[0][k] = b.lx; e_b[1][k] = b.ly; e_b[2][k] = b.lz; e_b[3][k] = b.hx; e_b[4][k] = b.hy; e_b[5][k] = b.hz;
         }
     }
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
     if (dbg == 1) return;
 
     // ---- ranges of the block's gaps, clamped to the window [g0-1, g0+T]; a range touching the window's rim is external
+    constexpr u32 M_EXT = 0xFFFFFFFFu;
     const int jmin = g0 ? (int)g0 - 1 : 0;
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
     auto wkey = [&](int j) -> u64 { return ((u64)s_key[j - (int)g0 + 1] << 32) | (u32)j; };
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
             int hi = p + 1 + (step >> 1);
             for (int t = step >> 2; t > 0; t >>= 1) if (inside(hi + t)) hi += t;
             const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
-            m_ext[k] = ext ? 1 : 0;
+            m_range[k] = ext ? M_EXT : 0u;
             if (!ext && (u32)(hi - lo + 1) > HP_HALF) {
                 m_range[k] = (u32)(lo - (int)g0) | ((u32)(hi - (int)g0) << 16);
                 my_lv[i] = 63 - c0;
@@ -512,21 +514,23 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
             const bool is_left = slot < 16;
             const u32 kk = (u32)(slot & 15);
             const u32 c_start = is_left ? L : P + 1u, c_len = is_left ? (P - L + 1u) : (R - P);
-            u32 idv = INV;
+            u32 idv = 0xFFFFu;
             if (have && kk < c_len) idv = e_id[c_start + kk];
-            const u32 vb = (u32)(__ballot(idv != INV) >> hbase);
+            const u32 vb = (u32)(__ballot(idv != 0xFFFFu) >> hbase);
             const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb >> 16);
             HpWork w; w.have = have; w.final_ = false; w.tL = g0 + L; w.cnt = nl + nr;
             w.id = INV; w.rep = INV; w.b = box_empty();
             if (have && (u32)slot < w.cnt) {
                 const u32 sp = (u32)slot < nl ? L + (u32)slot : P + 1u + ((u32)slot - nl);
-                w.id = e_id[sp]; w.rep = e_rep[sp];
+                const u32 ie = e_id[sp];
+                w.id = (ie & 0x8000u) ? ni + g0 + (ie & 0x7FFFu) : g0 + ie; w.rep = g0 + e_rep[sp];
                 w.b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
             }
             ploc_rounds<true>(w, nodes, zero_parent, ni, lane, slot, hbase, 0);
             if (have && slot < 16) {                 // storeIndices (:208-218) into the range's first 16 positions
                 const u32 d = L + (u32)slot;
-                e_id[d] = w.id; e_rep[d] = w.rep;
+                e_id[d] = (unsigned short)(w.id == INV ? 0xFFFFu : (w.id >= ni ? 0x8000u | (w.id - ni - g0) : w.id - g0));
+                e_rep[d] = (unsigned short)(w.rep - g0);
                 e_b[0][d] = w.b.lx; e_b[1][d] = w.b.ly; e_b[2][d] = w.b.lz; e_b[3][d] = w.b.hx; e_b[4][d] = w.b.hy; e_b[5][d] = w.b.hz;
             }
         }
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
         ev[i] = false; ev_pc[i] = 0;
         if (k < nleaf && pc < ni) {
             u32* rq = reinterpret_cast<u32*>(ranges + pc);
-            if (m_ext[k]) {
+            if (m_range[k] == M_EXT) {
                 const int p = (int)pc;
                 const u64 kp = gkey(p);
                 const int c0 = clz64(kp ^ gkey(p + 1));
@@ -578,9 +582,13 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
                 if (L == 0u) q = R;
                 else if (R == ni) q = L - 1u;
                 else q = ((wkey((int)R) ^ wkey((int)R + 1)) < (wkey((int)L - 1) ^ wkey((int)L))) ? R : L - 1u;
-                if (q < g0 || m_ext[q - g0]) {
+                if (q < g0 || m_range[q - g0] == M_EXT) {
 #pragma unroll
-                    for (int sidx = 0; sidx < 16; ++sidx) st_agent(cidx + L + sidx, entry(e_id[Lr + sidx], e_rep[Lr + sidx]));
+                    for (int sidx = 0; sidx < 16; ++sidx) {
+                        const u32 ie = e_id[Lr + sidx];
+                        const u32 idg = ie == 0xFFFFu ? INV : ((ie & 0x8000u) ? ni + g0 + (ie & 0x7FFFu) : g0 + ie);
+                        st_agent(cidx + L + sidx, entry(idg, g0 + e_rep[Lr + sidx]));
+                    }
                     st_agent(reinterpret_cast<u32*>(ranges + q) + (q == R ? 0 : 1), q == R ? L : R);
                     drain_stores();
                     const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(NT) void k_hploc_block(const bvh_aabb* __restrict__
         }
     }
     __syncthreads();                                 // the work lists are dead: their LDS becomes the block's ready list
-    u32* r_pc = e_id;
+    u32* r_pc = reinterpret_cast<u32*>(&e_b[0][0]);
 #pragma unroll
     for (int i = 0; i < PER; ++i) if (ev[i]) r_pc[atomicAdd(&s_nready, 1u)] = ev_pc[i];
     __syncthreads();
@@ -638,28 +646,33 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, c
 #ifndef HPB_NT
 #define HPB_NT 512
 #endif
-static void hpb_config(int* t, int* nt) {
-    *t = HPB_T; *nt = HPB_NT;
-    const char* e = getenv("BVH_HPB");                 // "T,NT" (measurements only)
-    if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) { *t = a; *nt = b; } }
+#ifndef HPB_OCC
+#define HPB_OCC 8
+#endif
+static void hpb_config(int* t, int* nt, int* occ) {
+    *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
+    const char* e = getenv("BVH_HPB");                 // "T,NT,OCC" (measurements only)
+    if (e) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { *t = a; *nt = b; *occ = c; } }
 }
-uint32_t hploc_block_tile() { int t, nt; hpb_config(&t, &nt); return (uint32_t)t; }
+uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return (uint32_t)t; }
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent,
                         uint32_t* d_queue, uint32_t* d_queue_count) {
     (void)hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
     (void)hipMemsetAsync(d_queue_count, 0, sizeof(u32), s);
-    int t, nt; hpb_config(&t, &nt);
+    int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
-#define HPB_LAUNCH(TT, NN) hipLaunchKernelGGL((k_hploc_block<TT, NN>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, \
+#define HPB_LAUNCH(TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, \
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, d_queue, d_queue_count, n, dbg)
     { KernelScope ks(s, "k_hploc_block");
-      if (t == 1024 && nt == 512) HPB_LAUNCH(1024, 512);
-      else if (t == 1024 && nt == 256) HPB_LAUNCH(1024, 256);
-      else if (t == 2048 && nt == 512) HPB_LAUNCH(2048, 512);
-      else if (t == 2048 && nt == 1024) HPB_LAUNCH(2048, 1024);
-      else if (t == 512 && nt == 256) HPB_LAUNCH(512, 256);
-      else HPB_LAUNCH(HPB_T, HPB_NT); }
+      if (t == 1024 && nt == 512 && occ == 8) HPB_LAUNCH(1024, 512, 8);
+      else if (t == 512 && nt == 256 && occ == 8) HPB_LAUNCH(512, 256, 8);
+      else if (t == 512 && nt == 256 && occ == 1) HPB_LAUNCH(512, 256, 1);
+      else if (t == 2048 && nt == 1024 && occ == 8) HPB_LAUNCH(2048, 1024, 8);
+      else if (t == 512 && nt == 128 && occ == 8) HPB_LAUNCH(512, 128, 8);
+      else if (t == 256 && nt == 128 && occ == 8) HPB_LAUNCH(256, 128, 8);
+      else if (occ == 1) HPB_LAUNCH(1024, 512, 1);
+      else HPB_LAUNCH(1024, 512, 8); }
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
