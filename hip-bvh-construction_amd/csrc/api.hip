@@ -50,7 +50,7 @@ struct bvh_ctx {
     u64* slots = nullptr;             // cap           (single-pass LBVH hand-off words)
     u32* parent = nullptr;            // 2*cap         (two-pass parent pointers / HPLOC parentIdx)
     u32* flags = nullptr;             // cap           (two-pass refit flags)
-    u32* cidx = nullptr;              // cap           (general u32 scratch: HPLOC level mode sorted level keys)
+    HplocScratch hploc{};             //               (hploc.dep is zeroed when the arena is allocated and stays clean)
     PlocScratch ploc{};
     u32* small = nullptr;             // 64 words: [0] root, [1] hploc node counter, [8..9] f64 SAH
     hipEvent_t ev[6] = {};
@@ -58,23 +58,20 @@ struct bvh_ctx {
 
 namespace {
 
-// HPLOC: asynchronous single-launch kernel below this size, level-synchronous launches above (62 small launches amortise)
-constexpr uint32_t HPLOC_LEVELS_MIN_N = 4000000;   // measured crossover on MI355X: async 3028 vs levels 2643 Mtris/s at 2 M, 3672 vs 4419 at 10 M
-enum HplocMode { HP_ASYNC, HP_LEVELS, HP_BLOCK };
-inline HplocMode hploc_mode(uint32_t n) {
-    const char* e = getenv("BVH_HPLOC_MODE");          // "async" / "levels" / "block" override (A/B measurements, tests)
-    if (e && e[0] == 'a') return HP_ASYNC;
-    if (e && e[0] == 'l') return HP_LEVELS;
-    if (e && e[0] == 'b') return n > 2 * hploc_block_tile() ? HP_BLOCK : HP_ASYNC;
-    return n >= HPLOC_LEVELS_MIN_N ? HP_LEVELS : HP_ASYNC;
+// HPLOC: one asynchronous launch below this size, LDS-tiled block kernel + external climb above (measured on MI355X: 1122 vs 966
+// Mtris/s at 262 k, 3005 vs 3416 at 2 M, 3848 vs 5616 at 10 M)
+constexpr uint32_t HPLOC_BLOCK_MIN_N = 1000000;
+inline bool hploc_use_block(uint32_t n) {
+    if (n <= 2 * hploc_block_tile()) return false;     // the root must cross tiles
+    const char* e = getenv("BVH_HPLOC_MODE");          // "async" / "block" override (A/B measurements, tests)
+    if (e && e[0] == 'a') return false;
+    if (e && e[0] == 'b') return true;
+    return n >= HPLOC_BLOCK_MIN_N;
 }
 // HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
 void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const u32* d_skeys, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves) {
-    switch (hploc_mode(n)) {
-        case HP_LEVELS: launch_hploc_levels(s, c->sort, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->keys, c->cidx, c->ploc.ids1, reinterpret_cast<uint4*>(c->sort.pairs0), c->small + 1); break;
-        case HP_BLOCK:  launch_hploc_block(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1, c->cidx, c->small + 2); break;
-        default:        launch_hploc(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->slots, reinterpret_cast<u64*>(c->parent), c->flags, c->small + 1); break;
-    }
+    if (hploc_use_block(n)) launch_hploc_block(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->hploc);
+    else launch_hploc(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->hploc);
 }
 
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
@@ -102,13 +99,19 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->slots = k.take<u64>(n);
     c->parent = k.take<u32>(2 * n);
     c->flags = k.take<u32>(n);
-    c->cidx = k.take<u32>(n);
+    c->hploc.recs = k.take<bvh2_node>(n);
+    c->hploc.dep = k.take<u64>(n);
+    c->hploc.queue_capacity = hploc_queue_capacity(cap);
+    c->hploc.queue_pc = k.take<u32>(c->hploc.queue_capacity);
+    c->hploc.queue_rng = k.take<u64>(c->hploc.queue_capacity);
+    c->hploc.queue_count = k.take<u32>(64 * 32);
     c->ploc.list0 = k.take<uint4>(2 * n);
     c->ploc.list1 = k.take<uint4>(2 * n);
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
     c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);
     c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH, [16..31] camera, [32..47] transform
+    c->hploc.zero_parent = c->small + 1;
     *total = k.off;
 }
 
@@ -122,6 +125,7 @@ int ensure_capacity(bvh_ctx* c, uint32_t n) {
     HIP_TRY(hipMalloc(&p, total));
     c->arena = p; c->arena_bytes = total; c->cap = n;
     carve(c, p, n, &total);
+    HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)n * sizeof(u64), c->stream));   // HPLOC dependency words: clean once, builds keep them clean
     return 0;
 }
 

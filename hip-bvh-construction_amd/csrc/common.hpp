@@ -78,6 +78,15 @@ __device__ __forceinline__ Box node_box_agent(const bvh2_node* n) {
     return { lo_f(a), hi_f(a), lo_f(b), hi_f(b), lo_f(c), hi_f(c) };
 #endif
 }
+// a whole 32-byte record {w0, w1, box} (Bvh2Node layout) written by node_store_agent, possibly by another workgroup of this launch
+__device__ __forceinline__ void rec_load_agent(const bvh2_node* n, u32& w0, u32& w1, Box& b) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f q0, q1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1) : "v"(n) : "memory");
+    w0 = __float_as_uint(q0.x); w1 = __float_as_uint(q0.y);
+    b = { q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+}
 // box part only (bytes 8..31) of a node whose child links were written earlier: 8-byte + 16-byte write-through stores
 __device__ __forceinline__ void node_box_store_agent(bvh2_node* n, const Box& b) {
     u64* q = reinterpret_cast<u64*>(n);

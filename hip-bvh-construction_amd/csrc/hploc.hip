@@ -12,23 +12,30 @@
 //  * one thread per LBVH gap p (between sorted leaves p and p+1) computes that node's leaf range [L,R] straight from the
 //    keys (common-prefix search; Karras/Apetrei trees are the same tree).  Ranges of <= 16 leaves need no work at all —
 //    the reference walks them with two global atomics per node just to discover them.
-//  * only "big" nodes (range > 16, ~n/11 of them) take part in a dependency protocol: counter[p] reaches 3 when the node's
-//    own thread (contributing 3 - #big children) and each big child (contributing 1) have arrived; whoever completes the
-//    count runs the merge task.  ~2 agent-scope atomics per big node instead of 2 per node.
 //  * a merge task occupies one 32-lane half of a wave64: the work list (id, rep, box) lives in registers, neighbours come
 //    from DPP wave shifts, partners through ds_bpermute, compaction through ds_permute.  Two tasks run side by side in the
-//    two halves.  No LDS allocation, no barriers, no reliance on store conflict order.
-//  * SetupClusters is fused: a leaf's PrimRef record is written when the leaf is first loaded as a cluster (exactly once);
-//    untouched child ranges are implicit (cluster id = n-1 + position), so the cluster-id array needs no initialisation.
+//    two halves.  No barriers inside a task, no reliance on store conflict order.
+//  * large inputs (k_hploc_block): a workgroup owns a tile of T consecutive sorted leaves and processes every node whose
+//    range lies inside the tile out of LDS, level by level; only the nodes that cross tile boundaries (the ancestors of the
+//    T-aligned gaps, ~9 % of the tasks at T = 1024) use the inter-workgroup protocol below, in a second launch (k_hploc_ext).
+//    Small inputs (k_hploc): one launch, every big node uses the protocol.
+//  * inter-workgroup protocol: ONE 64-bit word per node, dep[p] = {count:2 | R:30 | L:30}.  Only "big" nodes (range > 16)
+//    take part.  A finished left child adds {1, 0, its L}, a finished right child {1, its R, 0}; the node's own thread adds
+//    {3 - #big children, far ends of its small children}.  Whoever brings the count to 3 has the node's full range in the sum,
+//    resets the word to 0 (so the array is clean for the next build — no memset per build), runs the node's merge task and
+//    climbs.  Nobody waits, nobody searches for a range, and the range travels inside the atomic that publishes the child.
+//  * survivors of a finished range are published as 32-byte records {id, rep, box} at the range's first 16 positions (the
+//    reference's nodeIdx array holds ids only and every consumer gathers the boxes again): one dependent load per task.
+//  * SetupClusters is fused (a leaf's PrimRef is written when the leaf is first staged, exactly once).
 //  * node allocation: the reference takes node indices from ONE global counter (:163-167); a single word sustains ~90
 //    returning atomics/us on MI355X (~23 ms for a 10 M build).  Here every cluster carries the sorted position of its first
 //    leaf ("rep"); lists stay ordered by rep, a merge keeps the lower partner's rep and retires the absorbed partner's rep
 //    r in [1,n) exactly once — node index r-1 is a bijection onto [0,n-1).  The final merge moves whatever occupies node 0 to
 //    its own natural slot so that the root is node 0, as the reference guarantees.  Numbering depends on the topology only.
 //
-// Hand-off between waves (possibly on different XCDs): survivors (cidx) and node boxes written during the launch are
-// agent-scope write-through stores read back with agent-scope loads; a wave drains its stores (s_waitcnt vmcnt(0)) before
-// the agent-scope atomic on counter[] that publishes a finished range.
+// Hand-off between waves (possibly on different XCDs): records and node boxes written during a launch are agent-scope
+// write-through stores read back with agent-scope loads; a wave drains its stores (s_waitcnt vmcnt(0)) before the agent-scope
+// atomic on dep[] that publishes a finished range.
 #include <cstdlib>
 #include <cstdio>
 #include "common.hpp"
@@ -36,10 +43,8 @@
 
 namespace bvh {
 
-// ablation switch for measurements only (results are wrong when set): compiled in with -DBVH_ABLATION
-static inline int hploc_ablation() {
-    const char* e = getenv("BVH_HPLOC_DEBUG"); return e ? atoi(e) : 0;
-}
+// ablation switch for measurements only (results are incomplete when set)
+static inline int hploc_ablation() { const char* e = getenv("BVH_HPLOC_DEBUG"); return e ? atoi(e) : 0; }
 
 constexpr int HP_BLOCK = 256;
 constexpr u32 HP_HALF = 16;        // WarpSize/2 of the reference's wave32 (src/HplocKernel.h:195,238)
@@ -57,81 +62,70 @@ __device__ __forceinline__ Box shfl_box(const Box& b, int src) {
 __device__ __forceinline__ u32 push_u32(int dst, u32 v) { return (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)v); }
 __device__ __forceinline__ float push_f32(int dst, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v))); }
 
-// cidx entry: {cluster id, rep}
-__device__ __forceinline__ u64 entry(u32 id, u32 rep) { return (u64)id | ((u64)rep << 32); }
-
-// ---- one merge pass: every 32-lane half with `have` runs the plocMerge (:220-255) of the LBVH node at gap tP with leaf
-// range [tL, tR].  AGENT = true: survivors / node boxes may have been written by other workgroups of the same launch
-// (agent-scope loads and write-through stores); AGENT = false: everything read was written by earlier launches.
-template <bool AGENT> __device__ __forceinline__ u64 ld_e(const u64* p) { return AGENT ? ld_agent(p) : *p; }
-template <bool AGENT> __device__ __forceinline__ u32 ld_w(const u32* p) { return AGENT ? ld_agent(p) : *p; }
-template <bool AGENT> __device__ __forceinline__ void st_e(u64* p, u64 v) { if (AGENT) st_agent(p, v); else *p = v; }
-template <bool AGENT> __device__ __forceinline__ void st_w(u32* p, u32 v) { if (AGENT) st_agent(p, v); else *p = v; }
-template <bool AGENT> __device__ __forceinline__ Box node_box(const bvh2_node* n) {
-    if (AGENT) return node_box_agent(n);
-    const float* f = reinterpret_cast<const float*>(n) + 2;
-    return { f[0], f[1], f[2], f[3], f[4], f[5] };
-}
-template <bool AGENT> __device__ __forceinline__ void node_store(bvh2_node* n, u32 l, u32 r, const Box& b) {
-    if (AGENT) { node_store_agent(n, l, r, b); return; }
-    node_store_plain(n, l, r, b);
+// ---- dependency words -------------------------------------------------------------------------------------------------
+constexpr u64 DEP_MASK = (1ull << 30) - 1ull;
+__device__ __forceinline__ u64 dep_word(u32 count, u32 L, u32 R) { return ((u64)count << 60) | ((u64)R << 30) | (u64)L; }
+// add `mine` to dep[q]; true when that completes the node (count 3): then [L,R] is its range and the word is clean again
+__device__ __forceinline__ bool dep_arrive(u64* dep, u32 q, u64 mine, u32& L, u32& R) {
+    const u64 tot = __hip_atomic_fetch_add(dep + q, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+    if ((tot >> 60) != 3ull) return false;
+    st_agent(dep + q, 0ull);                       // nobody touches a completed node's word again during this build
+    L = (u32)(tot & DEP_MASK); R = (u32)((tot >> 30) & DEP_MASK);
+    return true;
 }
 
-struct HpEntry { u32 id, rep, prim; };   // prim: primitive index prefetched for implicit leaves, INV otherwise
-
-// loadIndices (:192-206): slots 0..15 <- left child, 16..31 <- right child; small children are implicit leaves
-template <bool AGENT>
-__device__ __forceinline__ HpEntry load_entry(bool have, u32 tL, u32 tR, u32 tP, const u32* __restrict__ svals, const u64* cidx, u32 ni, int slot) {
-        const bool is_left = slot < 16;
-        const u32 s = (u32)(slot & 15);
-        const u32 c_start = is_left ? tL : tP + 1, c_len = is_left ? (tP - tL + 1) : (tR - tP);
-        HpEntry en = { INV, INV, INV };
-        if (have) {
-            if (c_len > HP_HALF) { const u64 e = ld_e<AGENT>(cidx + c_start + s); en.id = (u32)e; en.rep = (u32)(e >> 32); }
-            else if (s < c_len) { en.rep = c_start + s; en.id = ni + en.rep; en.prim = svals[en.rep]; }
-        }
-        return en;
+// findParent (:66-81): the boundary gap with the longer common prefix (smaller xor) is the parent of range [L,R] (not the root)
+template <typename KeyAt>
+__device__ __forceinline__ u32 parent_gap(u32 L, u32 R, u32 ni, KeyAt key_at) {
+    if (L == 0u) return R;
+    if (R == ni) return L - 1u;
+    return ((key_at(R) ^ key_at(R + 1u)) < (key_at(L - 1u) ^ key_at(L))) ? R : L - 1u;
 }
 
 struct HpWork { u32 id, rep, cnt, tL; Box b; bool have, final_; };
 
-// left-pack the loaded entries, fetch their boxes (leaves: fused SetupClusters), return the work list of this half
-template <bool AGENT, bool SETUP = true>
-__device__ __forceinline__ HpWork prepare(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
-                                          const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, const bvh2_node* nodes,
-                                          u32 ni, int slot, int hbase) {
-        u32 id = en.id, rep = en.rep, prim = en.prim;
-        const u32 vb = (u32)(__ballot(id != INV) >> hbase);
-        const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
-        const u32 cnt = nl + nr;
-        {   // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
-            const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
-            const u32 ti = (u32)__shfl((int)id, src), tr = (u32)__shfl((int)rep, src), tp = (u32)__shfl((int)prim, src);
-            id = ((u32)slot < cnt) ? ti : INV; rep = tr; prim = tp;
-        }
-        Box b = box_empty();
-        if (id != INV) {
-            if (id >= ni) {   // first (and only) load of this leaf: fused SetupClusters (:44-47)
-                if (prim == INV) prim = svals[rep];
-                b = box_load(boxes + prim);
-                if (SETUP) {  // (SETUP = false: the block-local kernel wrote every PrimRef while staging its leaves)
-                    float* f = reinterpret_cast<float*>(leaves + rep);
-                    reinterpret_cast<u32*>(f)[0] = prim;
-                    f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-                }
-            } else b = node_box<AGENT>(nodes + id);                                                  // :242-246
-        }
-        HpWork w; w.id = id; w.rep = rep; w.cnt = cnt; w.tL = tL; w.b = b; w.have = have; w.final_ = have && tL == 0 && tR == ni;
-        return w;
+// loadIndices (:192-206) + the box fetch of plocMerge (:242-246): slots 0..15 <- left child [tL, tP], 16..31 <- right child
+// [tP+1, tR]; a child of > 16 leaves left its survivors as records, a smaller one is still its leaves; left-packed result.
+// SETUP: this is the first touch of those leaves — fused SetupClusters (:44-47); otherwise their PrimRefs exist already.
+template <bool SETUP>
+__device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals,
+                                            bvh_primref* leaves, const bvh2_node* recs, u32 ni, int slot, int hbase) {
+    const bool is_left = slot < 16;
+    const u32 s = (u32)(slot & 15);
+    const u32 c_start = is_left ? tL : tP + 1u, c_len = is_left ? (tP - tL + 1u) : (tR - tP);
+    u32 id = INV, rep = INV;
+    Box b = box_empty();
+    const bool leaf = have && c_len <= HP_HALF && s < c_len;
+    if (leaf) {
+        rep = c_start + s; id = ni + rep;
+        if (SETUP) {
+            const u32 prim = svals[rep];
+            b = box_load(boxes + prim);
+            float* f = reinterpret_cast<float*>(leaves + rep);
+            reinterpret_cast<u32*>(f)[0] = prim;
+            f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+        } else b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1));
+    }
+    if (have && c_len > HP_HALF) rec_load_agent(recs + c_start + s, id, rep, b);
+    // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
+    const u32 vb = (u32)(__ballot(id != INV) >> hbase);
+    const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
+    HpWork w; w.cnt = nl + nr; w.tL = tL; w.have = have; w.final_ = have && tL == 0 && tR == ni;
+    const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
+    const u32 ti = (u32)__shfl((int)id, src);
+    w.rep = (u32)__shfl((int)rep, src);
+    w.b = shfl_box(b, src);
+    w.id = ((u32)slot < w.cnt) ? ti : INV;
+    return w;
 }
 
-// PLOC rounds until <= 16 clusters (root: 1) remain; the work list stays in registers (w is updated in place)
-template <bool AGENT>
-__device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
+// PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
+// registers (w is updated in place).  Node stores are agent-scope write-through: other workgroups read them later.
+__device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase) {
         const bool have = w.have, final_ = w.final_;
         u32 id = w.id, rep = w.rep, cnt = w.cnt;
         Box b = w.b;
-        const u32 threshold = dbg == 2 ? 64u : (final_ ? 1u : HP_HALF);
+        const u32 threshold = final_ ? 1u : HP_HALF;
         while (__ballot(have && cnt > threshold)) {
             const bool act = have && cnt > threshold;
             // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
@@ -167,17 +161,17 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
                     // natural slot and re-point its parent
                     const u64* q0 = reinterpret_cast<const u64*>(nodes);
                     u64* qs = reinterpret_cast<u64*>(nodes + at);
-                    const u64 w0 = ld_e<AGENT>(q0 + 0), w1 = ld_e<AGENT>(q0 + 1), w2 = ld_e<AGENT>(q0 + 2), w3 = ld_e<AGENT>(q0 + 3);
-                    st_e<AGENT>(qs + 0, w0); st_e<AGENT>(qs + 1, w1); st_e<AGENT>(qs + 2, w2); st_e<AGENT>(qs + 3, w3);
+                    const u64 w0 = ld_agent(q0 + 0), w1 = ld_agent(q0 + 1), w2 = ld_agent(q0 + 2), w3 = ld_agent(q0 + 3);
+                    st_agent(qs + 0, w0); st_agent(qs + 1, w1); st_agent(qs + 2, w2); st_agent(qs + 3, w3);
                     if (l == 0u) l = at;
                     else if (r == 0u) r = at;
                     else {
-                        const u32 pw = ld_w<AGENT>(zero_parent);
-                        st_w<AGENT>(reinterpret_cast<u32*>(nodes + (pw >> 1)) + (pw & 1u), at);
+                        const u32 pw = ld_agent(zero_parent);
+                        st_agent(reinterpret_cast<u32*>(nodes + (pw >> 1)) + (pw & 1u), at);
                     }
                     at = 0u;
-                } else if (l == 0u || r == 0u) st_w<AGENT>(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
-                node_store<AGENT>(nodes + at, l, r, b);
+                } else if (l == 0u || r == 0u) st_agent(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
+                node_store_agent(nodes + at, l, r, b);
                 id = at;
             }
             // compaction: survivors and merged clusters keep their order (:176-187 as "valid slots write to their rank").
@@ -194,28 +188,12 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
         w.id = id; w.rep = rep; w.cnt = cnt; w.b = b;
 }
 
-// PLOC rounds, then storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
-template <bool AGENT>
-__device__ __forceinline__ void reduce_and_store(HpWork w, bvh2_node* nodes, u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
-        ploc_rounds<AGENT>(w, nodes, zero_parent, ni, lane, slot, hbase, dbg);
-        if (w.have && !w.final_ && slot < 16) st_e<AGENT>(cidx + w.tL + slot, entry(w.id, w.rep));
-}
-
-template <bool AGENT, bool SETUP = true>
-__device__ __forceinline__ void merge_exec(bool have, u32 tL, u32 tR, HpEntry en, const bvh_aabb* __restrict__ boxes,
-                                           const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
-                                           u64* cidx, u32* zero_parent, u32 ni, int lane, int slot, int hbase, int dbg) {
-    reduce_and_store<AGENT>(prepare<AGENT, SETUP>(have, tL, tR, en, boxes, svals, leaves, nodes, ni, slot, hbase), nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
-}
-
 // ---- the asynchronous part: run ready merge tasks, two per pass (one per 32-lane half of the wave), then hand the finished
-// range to the parent node; whoever completes the parent's dependency count (3) runs it next.  No waiting anywhere.
-// PROP = true: a node's range is assembled bottom-up — the finishing left child stores its L into the low half of ranges[q], the
-// right child its R into the high half (the parent's own thread supplies the half of a small child), so nobody searches.
-template <bool SETUP, bool PROP = false>
+// range to the parent node (dep_arrive); a lane that completes its parent runs it next.  No waiting anywhere.
+template <bool SETUP>
 __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
-                                            const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes, u64* cidx,
-                                            u64* ranges, u32* counter, u32* zero_parent, u32 ni, int lane, int dbg) {
+                                            const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs,
+                                            u64* dep, u32* zero_parent, u32 ni, int lane) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
     while (true) {
         const u64 rm = __ballot(ready);
@@ -227,43 +205,37 @@ __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, co
         const bool have = own >= 0;
         const int osrc = have ? own : 0;
         const u32 tL = (u32)__shfl((int)L, osrc), tR = (u32)__shfl((int)R, osrc), tP = (u32)__shfl((int)pc, osrc);
-        merge_exec<true, SETUP>(have, tL, tR, load_entry<true>(have, tL, tR, tP, svals, cidx, ni, slot), boxes, svals, leaves, nodes, cidx, zero_parent, ni, lane, slot, hbase, dbg);
+        // the owners look up their parent now: the four key loads fly while the task runs
+        const bool owner = ready && (lane == ownA || lane == ownB);
+        u32 q = INV;
+        if (owner && !(L == 0u && R == ni)) q = parent_gap(L, R, ni, [&](u32 j) { return aug_key(skeys, j); });
 
-        // -- the owners hand their finished range to the parent node
-        if (ready && (lane == ownA || lane == ownB)) {
+        HpWork w = load_work<SETUP>(have, tL, tR, tP, boxes, svals, leaves, recs, ni, slot, hbase);
+        ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase);
+        // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
+        if (have && !w.final_ && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);
+
+        if (owner) {
             ready = false;
-            if (!(L == 0 && R == ni)) {
-                // findParent (:66-81): the boundary gap with the longer common prefix (smaller xor) is the parent
-                u32 q;
-                if (L == 0) q = R;
-                else if (R == ni) q = L - 1;
-                else q = ((aug_key(skeys, R) ^ aug_key(skeys, R + 1)) < (aug_key(skeys, L - 1) ^ aug_key(skeys, L))) ? R : L - 1;
-                if (PROP) st_agent(reinterpret_cast<u32*>(ranges + q) + (q == R ? 0 : 1), q == R ? L : R);
-                drain_stores();                 // the wave's node / survivor stores are in memory before the count moves
-                const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + 1u == 3u) {
-                    compiler_fence();
-                    const u64 rg = ld_agent(ranges + q);
-                    pc = q; L = (u32)rg; R = (u32)(rg >> 32); ready = true;
-                }
+            if (q != INV) {
+                drain_stores();                 // the wave's node / record stores are in memory before the count moves
+                ready = dep_arrive(dep, q, q == R ? dep_word(1u, L, 0u) : dep_word(1u, 0u, R), L, R);
+                pc = q;
             }
         }
     }
 }
 
-#ifndef HP_WAVES
-#define HP_WAVES 1
-#endif
-__global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
-                                                    const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
-                                                    bvh2_node* nodes, u64* cidx, u64* ranges, u32* counter, u32* zero_parent, u32 n, int dbg) {
+// Small inputs: one launch.  Phase 1: range of every gap from the keys; big nodes enter the dependency protocol.  Phase 2: climb.
+__global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+                                                    const u32* __restrict__ svals, bvh_primref* leaves,
+                                                    bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 n, int dbg) {
     const int lane = threadIdx.x & (WAVE - 1);
     const u32 ni = n - 1;
     u32 pc = blockIdx.x * HP_BLOCK + threadIdx.x;      // LBVH gap / node this lane currently speaks for
     u32 L = 0, R = 0;
     bool ready = false;
 
-    // ---- phase 1: range of node pc from the keys; dependency bookkeeping for big nodes ---------------------------------
     // The block's key window [g0 - 256, g0 + 512] sits in LDS: almost every probe of the common-prefix searches lands there
     // (a dependent L2 round trip per probe otherwise); only ranges reaching beyond the window probe global memory.
     __shared__ u32 s_keys[HP_BLOCK * 3 + 1];
@@ -296,105 +268,14 @@ __global__ __launch_bounds__(HP_BLOCK, HP_WAVES) void k_hploc(const bvh_aabb* __
         }
         const u32 size = R - L + 1;
         if (size > HP_HALF || size == n) {                                       // :303-305 (size > 16 or root)
-            const u32 e = ((pc - L + 1) > HP_HALF ? 1u : 0u) + ((R - pc) > HP_HALF ? 1u : 0u);
+            const bool lbig = (pc - L + 1) > HP_HALF, rbig = (R - pc) > HP_HALF;
+            const u32 e = (lbig ? 1u : 0u) + (rbig ? 1u : 0u);
             if (e == 0) ready = true;
-            else {
-                st_agent(ranges + pc, (u64)L | ((u64)R << 32));
-                drain_stores();
-                const u32 old = __hip_atomic_fetch_add(counter + pc, 3u - e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ready = (old + (3u - e)) == 3u;
-            }
+            else ready = dep_arrive(dep, pc, dep_word(3u - e, lbig ? 0u : L, rbig ? 0u : R), L, R);
         }
     }
-
     if (dbg == 1) return;
-    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, cidx, ranges, counter, zero_parent, ni, lane, dbg);
-}
-
-// =====================================================================================================================
-// Level-synchronous variant for large inputs.
-//
-// In the LBVH hierarchy a parent's common prefix is strictly shorter than its children's, so "process nodes by decreasing
-// prefix length c0" is a topological order that needs no dependency tracking at all: k_hp_plan computes every node's range
-// and c0 from the keys, the one-sweep sort (one 8-bit pass) groups the big nodes by level 63 - c0, and one launch per level
-// runs that level's merge tasks — two per wave64, always paired, with plain (cached) loads and stores, no atomics, no
-// drains: the kernel boundary is the hand-off.  Empty levels cost one ~2 us launch each.
-// =====================================================================================================================
-constexpr u32 HP_NO_TASK = 0xFFu;
-
-__global__ __launch_bounds__(HP_BLOCK) void k_hp_plan(const u32* __restrict__ skeys, u64* __restrict__ ranges,
-                                                      u32* __restrict__ level_keys, u32 n) {
-    __shared__ u32 s_keys[HP_BLOCK * 3 + 1];
-    const u32 ni = n - 1;
-    const u32 pc = blockIdx.x * HP_BLOCK + threadIdx.x;
-    const int g0 = (int)(blockIdx.x * HP_BLOCK);
-    const int w0 = g0 - HP_BLOCK;
-    for (int k = threadIdx.x; k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : 0u; }
-    __syncthreads();
-    if (pc >= ni) return;
-    auto key_at = [&](int j) -> u64 {
-        const u32 k = ((u32)(j - w0) <= (u32)(HP_BLOCK * 3)) ? s_keys[j - w0] : skeys[j];
-        return ((u64)k << 32) | (u32)j;
-    };
-    const int p = (int)pc;
-    const u64 kp = key_at(p);
-    const int c0 = clz64(kp ^ key_at(p + 1));
-    auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(key_at(j) ^ kp) >= c0; };
-    int step = 1;
-    while (inside(p - step)) step <<= 1;
-    int lo = p - (step >> 1);
-    for (int t = step >> 2; t > 0; t >>= 1) if (inside(lo - t)) lo -= t;
-    step = 1;
-    while (inside(p + 1 + step)) step <<= 1;
-    int hi = p + 1 + (step >> 1);
-    for (int t = step >> 2; t > 0; t >>= 1) if (inside(hi + t)) hi += t;
-    const u32 size = (u32)(hi - lo + 1);
-    const bool big = size > HP_HALF || size == n;
-    level_keys[pc] = big ? (u32)(63 - c0) : HP_NO_TASK;
-    if (big) ranges[pc] = (u64)(u32)lo | ((u64)(u32)hi << 32);
-}
-
-// task records in level order: {gap, L, R, -} — one 16-byte load instead of the dependent task id -> range pair
-__global__ __launch_bounds__(256) void k_hp_pack(const u32* __restrict__ level_offsets, const u32* __restrict__ task_ids,
-                                                 const u64* __restrict__ ranges, uint4* __restrict__ tasks) {
-    const u32 total = level_offsets[62];                      // end of the last level (key 255 = "no task" sorts behind)
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const u32 p = task_ids[i]; const u64 rg = ranges[p];
-        tasks[i] = make_uint4(p, (u32)rg, (u32)(rg >> 32), 0u);
-    }
-}
-
-// level_offsets: the sort's exclusive digit offsets (hist after k_scan_hist): tasks of level v are tasks[off[v] .. off[v+1])
-#ifndef HP_LEVEL_WAVES
-#define HP_LEVEL_WAVES 1
-#endif
-__global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32* __restrict__ level_offsets, int level, const uint4* __restrict__ tasks,
-                                                       const bvh_aabb* __restrict__ boxes,
-                                                       const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
-                                                       u64* cidx, u32* zero_parent, u32 n) {
-    const u32 base = level_offsets[level], count = level_offsets[level + 1] - base;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
-    const u32 ni = n - 1;
-    const u32 stride = gridDim.x * (HP_BLOCK / 32);
-    const u32 t0 = blockIdx.x * (HP_BLOCK / 32) + (threadIdx.x >> 6) * 2;          // wave-uniform first task of the wave
-    // The merge rounds are short next to the dependent loads in front of them (task record -> cluster entries -> boxes;
-    // measured: waves parked on s_waitcnt 66 % of the time), and the compiler serialises loads prefetched across the loop
-    // back-edge.  So every iteration carries TWO independent task pairs (A, B): their loads are issued stage by stage
-    // together, then the rounds run back to back — twice the memory-level parallelism per wave.
-    for (u32 tw = t0; tw < count; tw += 2 * stride) {                                // wave-uniform
-        const u32 tA = tw + (u32)half, tB = tw + stride + (u32)half;
-        const bool hA = tA < count, hB = tB < count;
-        uint4 rA = make_uint4(0, 0, 0, 0), rB = make_uint4(0, 0, 0, 0);
-        if (hA) rA = tasks[base + tA];
-        if (hB) rB = tasks[base + tB];
-        const HpEntry eA = load_entry<false>(hA, rA.y, rA.z, rA.x, svals, cidx, ni, slot);
-        const HpEntry eB = load_entry<false>(hB, rB.y, rB.z, rB.x, svals, cidx, ni, slot);
-        const HpWork wA = prepare<false>(hA, rA.y, rA.z, eA, boxes, svals, leaves, nodes, ni, slot, hbase);
-        const HpWork wB = prepare<false>(hB, rB.y, rB.z, eB, boxes, svals, leaves, nodes, ni, slot, hbase);
-        reduce_and_store<false>(wA, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
-        reduce_and_store<false>(wB, nodes, cidx, zero_parent, ni, lane, slot, hbase, 0);
-    }
+    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, ni, lane);
 }
 
 // =====================================================================================================================
@@ -406,33 +287,44 @@ __global__ __launch_bounds__(HP_BLOCK, HP_LEVEL_WAVES) void k_hp_level(const u32
 // 16 positions exactly like the reference's nodeIdx array) in LDS, and walks its local hierarchy level by level (level =
 // 63 - common prefix; a parent's prefix is strictly shorter than its children's) with one barrier per non-empty level.  A
 // local task therefore has no global load in front of its PLOC rounds and only the 32-byte node store behind them.
-// Nodes whose range crosses a block boundary ("external": the ancestors of the T-aligned gaps) run afterwards under the
-// asynchronous dependency protocol of k_hploc (async_climb): the block publishes the survivors of its maximal local ranges
-// to global memory and moves the parents' counters.  One launch, no per-level kernel boundaries, no plan/sort passes.
+// Nodes whose range crosses a block boundary ("external": the ancestors of the T-aligned gaps) use the dependency protocol:
+// the block publishes the records of its maximal local ranges and its external nodes' own contributions; nodes completed by
+// that are queued (HPQ_SUB sub-queues, one atomic per block) for k_hploc_ext, which climbs from there.
 // =====================================================================================================================
+constexpr u32 HPQ_SUB = 64;        // sub-queues (a single queue head would serialise one atomic per block)
+constexpr u32 HPQ_LOCAL = 32;      // ready items a block aggregates in LDS before falling back to one atomic per item
+
+__device__ __forceinline__ void queue_put(u32* q_pc, u64* q_rng, u32 q_cap, u32 sub, u32 at_in_sub, u32 pc, u32 L, u32 R) {
+    const size_t at = (size_t)sub * q_cap + at_in_sub;
+    q_pc[at] = pc; q_rng[at] = (u64)L | ((u64)R << 32);
+}
+
 template <int T, int NT, int OCC>
 __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
-                                                    bvh2_node* nodes, u64* cidx, u64* ranges, u32* counter, u32* zero_parent,
-                                                    u32* queue, u32* queue_count, u32 n, int dbg) {
+                                                    bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent,
+                                                    u32* q_pc, u64* q_rng, u32* q_count, u32 q_cap, u32 n, int dbg) {
     constexpr int PER = T / NT;                      // leaf positions (and gaps) per thread
     constexpr int NW = NT / WAVE;
-    static_assert(T % NT == 0 && T <= 32768, "block-local HPLOC tile");
+    static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
     __shared__ u32 s_key[T + 2];                     // sorted keys of positions g0-1 .. g0+T
     // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
     // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
     __shared__ unsigned short e_id[T], e_rep[T];     // id: 0x8000 | k = leaf ni + g0 + k;  k = node g0 + k;  0xFFFF = invalid
-    __shared__ float e_b[6][T];                      // (later: the block's ready list)
+    __shared__ float e_b[6][T];
     __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
-    __shared__ unsigned short s_task[T];             // local big nodes grouped by level
+    __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
     __shared__ u32 s_cnt[64], s_off[64];
-    __shared__ u32 s_nready;
+    __shared__ u32 s_npub, s_nready, s_qbase;
+    __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
     const u32 ni = n - 1;
     const u32 g0 = blockIdx.x * (u32)T;
     const u32 nleaf = (n - g0) < (u32)T ? (n - g0) : (u32)T;
+    const u32 sub = blockIdx.x % HPQ_SUB;
+    auto decode_id = [&](u32 ie) -> u32 { return ie == 0xFFFFu ? INV : ((ie & 0x8000u) ? ni + g0 + (ie & 0x7FFFu) : g0 + ie); };
 
     // ---- stage the block: leaves (SetupClusters :44-47, fused), keys -------------------------------------------------
 #pragma unroll
@@ -450,7 +342,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
     for (int k = tid; k < T + 2; k += NT) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : 0u; }
     if (tid < 64) s_cnt[tid] = 0u;
-    if (tid == 0) s_nready = 0u;
+    if (tid == 0) { s_npub = 0u; s_nready = 0u; }
     __syncthreads();
     if (dbg == 1) return;
 
@@ -498,8 +390,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #pragma unroll
     for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)((u32)tid + (u32)i * NT);
     __syncthreads();
-
     if (dbg == 2) return;
+
     // ---- local hierarchy, deepest level first; two tasks per wave pass ----------------------------------------------------
     for (int lv = 0; lv < 62; ++lv) {
         const u32 c = s_cnt[lv];
@@ -522,11 +414,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             w.id = INV; w.rep = INV; w.b = box_empty();
             if (have && (u32)slot < w.cnt) {
                 const u32 sp = (u32)slot < nl ? L + (u32)slot : P + 1u + ((u32)slot - nl);
-                const u32 ie = e_id[sp];
-                w.id = (ie & 0x8000u) ? ni + g0 + (ie & 0x7FFFu) : g0 + ie; w.rep = g0 + e_rep[sp];
+                w.id = decode_id(e_id[sp]); w.rep = g0 + e_rep[sp];
                 w.b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
             }
-            ploc_rounds<true>(w, nodes, zero_parent, ni, lane, slot, hbase, 0);
+            ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase);
             if (have && slot < 16) {                 // storeIndices (:208-218) into the range's first 16 positions
                 const u32 d = L + (u32)slot;
                 e_id[d] = (unsigned short)(w.id == INV ? 0xFFFFu : (w.id >= ni ? 0x8000u | (w.id - ni - g0) : w.id - g0));
@@ -536,110 +427,116 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         }
         __syncthreads();
     }
-    drain_stores();                                  // every wave's node stores are in memory before the block publishes
-    __syncthreads();
+    drain_stores();                                  // every wave's node stores are in memory before anything is published (step 2)
     if (dbg == 3) return;
 
-    // ---- hand-over: survivors of the maximal local ranges go to global memory and move their (external) parent's count; the
-    // block's external nodes contribute what their own thread knows (which children are small, and those children's far ends).
-    // Nodes whose count completes here are queued for k_hploc_ext.
+    // ---- hand-over, step 1 (one thread per gap): an external node adds its own contribution — which children are small, and
+    // those children's far ends (child [L,p] is big iff leaf p-16 shares the prefix, child [p+1,R] iff leaf p+17 does);
+    // a maximal local node (parent external) is listed for publication.  (s_task is dead as a task list: every thread is past
+    // the level loop's last barrier.)
     auto gkey = [&](int j) -> u64 {
         const u32 kv = (j >= jmin && j <= jmax) ? s_key[j - (int)g0 + 1] : skeys[j];
         return ((u64)kv << 32) | (u32)j;
     };
-    bool ev[PER]; u32 ev_pc[PER];
+    auto ready_push = [&](u32 pc, u32 L, u32 R) {
+        const u32 at = atomicAdd(&s_nready, 1u);
+        if (at < HPQ_LOCAL) { r_pc[at] = pc; r_L[at] = L; r_R[at] = R; }
+        else queue_put(q_pc, q_rng, q_cap, sub, atomicAdd(q_count + sub * 32u, 1u), pc, L, R);   // (pathological tiles only)
+    };
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const u32 k = (u32)tid + (u32)i * NT;
         const u32 pc = g0 + k;
-        ev[i] = false; ev_pc[i] = 0;
         if (k < nleaf && pc < ni) {
-            u32* rq = reinterpret_cast<u32*>(ranges + pc);
             if (m_range[k] == M_EXT) {
                 const int p = (int)pc;
                 const u64 kp = gkey(p);
                 const int c0 = clz64(kp ^ gkey(p + 1));
                 auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(gkey(j) ^ kp) >= c0; };
-                // child [L, p] is big iff leaf p-16 is inside; child [p+1, R] is big iff leaf p+17 is inside
                 const bool lbig = inside(p - (int)HP_HALF), rbig = inside(p + 1 + (int)HP_HALF);
                 int lo = p, hi = p + 1;
                 if (!lbig) { for (int t = 8; t > 0; t >>= 1) if (inside(lo - t)) lo -= t; }          // L in [p-15, p]
                 if (!rbig) { for (int t = 8; t > 0; t >>= 1) if (inside(hi + t)) hi += t; }          // R in [p+1, p+16]
                 const u32 e = (lbig ? 1u : 0u) + (rbig ? 1u : 0u);
-                if (e == 0u) {
-                    if ((u32)(hi - lo + 1) > HP_HALF) { rq[0] = (u32)lo; rq[1] = (u32)hi; ev[i] = true; ev_pc[i] = pc; }   // read by the next launch
-                } else {
-                    if (!lbig) st_agent(rq + 0, (u32)lo);
-                    if (!rbig) st_agent(rq + 1, (u32)hi);
-                    drain_stores();
-                    const u32 old = __hip_atomic_fetch_add(counter + pc, 3u - e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((old + (3u - e)) == 3u) { ev[i] = true; ev_pc[i] = pc; }
+                if (e == 0u) { if ((u32)(hi - lo + 1) > HP_HALF) ready_push(pc, (u32)lo, (u32)hi); }
+                else {
+                    u32 L, R;
+                    if (dep_arrive(dep, pc, dep_word(3u - e, lbig ? 0u : (u32)lo, rbig ? 0u : (u32)hi), L, R)) ready_push(pc, L, R);
                 }
             } else if (my_lv[i] >= 0) {
                 const u32 rg = m_range[k];
-                const u32 Lr = rg & 0xFFFFu, L = g0 + Lr, R = g0 + (rg >> 16);
-                u32 q;                                                               // findParent (:66-81)
-                if (L == 0u) q = R;
-                else if (R == ni) q = L - 1u;
-                else q = ((wkey((int)R) ^ wkey((int)R + 1)) < (wkey((int)L - 1) ^ wkey((int)L))) ? R : L - 1u;
-                if (q < g0 || m_range[q - g0] == M_EXT) {
-#pragma unroll
-                    for (int sidx = 0; sidx < 16; ++sidx) {
-                        const u32 ie = e_id[Lr + sidx];
-                        const u32 idg = ie == 0xFFFFu ? INV : ((ie & 0x8000u) ? ni + g0 + (ie & 0x7FFFu) : g0 + ie);
-                        st_agent(cidx + L + sidx, entry(idg, g0 + e_rep[Lr + sidx]));
-                    }
-                    st_agent(reinterpret_cast<u32*>(ranges + q) + (q == R ? 0 : 1), q == R ? L : R);
-                    drain_stores();
-                    const u32 old = __hip_atomic_fetch_add(counter + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old + 1u == 3u) { ev[i] = true; ev_pc[i] = q; }
-                }
+                const u32 L = g0 + (rg & 0xFFFFu), R = g0 + (rg >> 16);
+                const u32 q = parent_gap(L, R, ni, [&](u32 j) { return wkey((int)j); });
+                if (q < g0 || m_range[q - g0] == M_EXT) s_task[atomicAdd(&s_npub, 1u)] = (unsigned short)(k | (q == R ? 0u : 0x8000u));
             }
         }
     }
-    __syncthreads();                                 // the work lists are dead: their LDS becomes the block's ready list
-    u32* r_pc = reinterpret_cast<u32*>(&e_b[0][0]);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) if (ev[i]) r_pc[atomicAdd(&s_nready, 1u)] = ev_pc[i];
     __syncthreads();
-    const u32 nready = s_nready;                     // <= T (one event per gap at most)
+    // ---- step 2 (16 lanes per node): the records of a maximal local range go to global memory, then its parent's count moves
+    {
+        const u32 npub = s_npub;
+        const int grp = tid >> 4, sl = tid & 15;
+        const u32 trips = (npub + (u32)(NT / 16) - 1u) / (u32)(NT / 16);                 // block-uniform
+        for (u32 it = 0; it < trips; ++it) {
+            const u32 j = it * (u32)(NT / 16) + (u32)grp;
+            const bool on = j < npub;
+            u32 L = 0, R = 0; bool right = false;
+            if (on) {
+                const u32 tk = s_task[j];
+                const u32 rg = m_range[tk & 0x7FFFu];
+                const u32 Lr = rg & 0xFFFFu; L = g0 + Lr; R = g0 + (rg >> 16); right = (tk & 0x8000u) != 0u;
+                const u32 sp = Lr + (u32)sl;
+                const Box b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
+                node_store_agent(recs + L + sl, decode_id(e_id[sp]), g0 + e_rep[sp], b);
+            }
+            drain_stores();                          // the wave's record (and, earlier, node) stores are in memory ...
+            if (on && sl == 0) {                     // ... before lane 0 of each group publishes
+                const u32 q = right ? L - 1u : R;
+                u32 pL, pR;
+                if (dep_arrive(dep, q, right ? dep_word(1u, 0u, R) : dep_word(1u, L, 0u), pL, pR)) ready_push(q, pL, pR);
+            }
+        }
+    }
+    __syncthreads();
     if (dbg == 4) return;
+    // ---- step 3: the block's ready nodes join its sub-queue (one atomic per block)
+    const u32 nready = s_nready < HPQ_LOCAL ? s_nready : HPQ_LOCAL;
     if (nready) {
-        if (tid == 0) s_off[0] = atomicAdd(queue_count, nready);
+        if (tid == 0) s_qbase = atomicAdd(q_count + sub * 32u, nready);
         __syncthreads();
-        const u32 at = s_off[0];
-        for (u32 i = (u32)tid; i < nready; i += (u32)NT) queue[at + i] = r_pc[i];
+        for (u32 i = (u32)tid; i < nready; i += (u32)NT) queue_put(q_pc, q_rng, q_cap, sub, s_qbase + i, r_pc[i], r_L[i], r_R[i]);
     }
 }
 
-// External nodes (ranges crossing the tiles of k_hploc_block): the queue holds the nodes whose dependencies were complete when
-// the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
+// External nodes (ranges crossing the tiles of k_hploc_block): the sub-queues hold the nodes whose dependencies were complete
+// when the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
 __global__ __launch_bounds__(256) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
-                                                   const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, bvh2_node* nodes,
-                                                   u64* cidx, u64* ranges, u32* counter, u32* zero_parent,
-                                                   const u32* __restrict__ queue, const u32* __restrict__ queue_count, u32 n) {
+                                                   const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes,
+                                                   bvh2_node* recs, u64* dep, u32* zero_parent,
+                                                   const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, const u32* __restrict__ q_count, u32 q_cap, u32 n) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const u32 total = *queue_count;
     const u32 nwaves = gridDim.x * (256 / WAVE);
     const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-    for (u32 base = wid * 2u; base < total; base += nwaves * 2u) {      // wave-uniform
+    const u32 sub = wid % HPQ_SUB, wsub = wid / HPQ_SUB, nwsub = nwaves / HPQ_SUB;       // (nwaves is a multiple of HPQ_SUB)
+    const u32 total = q_count[sub * 32u];
+    for (u32 base = wsub * 2u; base < total; base += nwsub * 2u) {       // wave-uniform
         const u32 idx = base + (u32)(lane >> 5);
         const bool ready = (lane & 31) == 0 && idx < total;
         u32 pc = 0, L = 0, R = 0;
-        if (ready) { pc = queue[idx]; const u64 rg = ranges[pc]; L = (u32)rg; R = (u32)(rg >> 32); }
-        async_climb<false, true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, cidx, ranges, counter, zero_parent, n - 1, lane, 0);
+        if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
+        async_climb<false>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane);
     }
 }
 
 void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                  void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent) {
-    hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
+                  void* d_nodes, void* d_leaves, const HplocScratch& sc) {
     const u32 gaps = n - 1;
-    { KernelScope ks(s, "k_hploc"); hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
-                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, n, hploc_ablation()); }
+    KernelScope ks(s, "k_hploc");
+    hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
+                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
 }
 
-// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  queue: u32[n] scratch; queue_count: one word.
+// Block-local HPLOC for large n (n > 2 tiles: the root is never local).
 #ifndef HPB_T
 #define HPB_T 1024
 #endif
@@ -655,48 +552,28 @@ static void hpb_config(int* t, int* nt, int* occ) {
     if (e) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { *t = a; *nt = b; *occ = c; } }
 }
 uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return (uint32_t)t; }
+// every tile may queue up to 2T nodes (its own external nodes + the parents of its maximal local ones), tiles >= 128 leaves
+size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SUB + 2) * 2 * 128 * HPQ_SUB; }
+
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent,
-                        uint32_t* d_queue, uint32_t* d_queue_count) {
-    (void)hipMemsetAsync(d_counter, 0, (size_t)n * sizeof(u32), s);
-    (void)hipMemsetAsync(d_queue_count, 0, sizeof(u32), s);
+                        void* d_nodes, void* d_leaves, const HplocScratch& sc) {
+    (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
     int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
+    const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);
 #define HPB_LAUNCH(TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, \
-                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_ranges, d_counter, d_zero_parent, d_queue, d_queue_count, n, dbg)
+                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg)
     { KernelScope ks(s, "k_hploc_block");
-      if (t == 1024 && nt == 512 && occ == 8) HPB_LAUNCH(1024, 512, 8);
-      else if (t == 512 && nt == 256 && occ == 8) HPB_LAUNCH(512, 256, 8);
-      else if (t == 512 && nt == 256 && occ == 1) HPB_LAUNCH(512, 256, 1);
-      else if (t == 2048 && nt == 1024 && occ == 8) HPB_LAUNCH(2048, 1024, 8);
-      else if (t == 512 && nt == 128 && occ == 8) HPB_LAUNCH(512, 128, 8);
+      if (t == 512 && nt == 256 && occ == 8) HPB_LAUNCH(512, 256, 8);
       else if (t == 256 && nt == 128 && occ == 8) HPB_LAUNCH(256, 128, 8);
+      else if (t == 2048 && nt == 1024 && occ == 8) HPB_LAUNCH(2048, 1024, 8);
       else if (occ == 1) HPB_LAUNCH(1024, 512, 1);
       else HPB_LAUNCH(1024, 512, 8); }
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
     hipLaunchKernelGGL(k_hploc_ext, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
-                       d_cluster_idx, d_ranges, d_counter, d_zero_parent, (const u32*)d_queue, (const u32*)d_queue_count, n);
-}
-
-// Level-synchronous HPLOC for large n.  level_keys / task_keys / task_ids: u32[n] scratch; sc: the sort's scratch (re-armed here).
-void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                         void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
-                         uint32_t* d_task_keys, uint32_t* d_task_ids, uint4* d_tasks, uint32_t* d_zero_parent) {
-    const u32 gaps = n - 1;
-    { KernelScope ks(s, "k_hp_plan"); hipLaunchKernelGGL(k_hp_plan, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, d_skeys, d_ranges, d_level_keys, n); }
-    sort_prepare(s, sc, gaps);
-    sort_pairs(s, sc, d_level_keys, nullptr, gaps, d_task_keys, d_task_ids, 0, 8, false);     // one pass; sc.hist = level offsets
-    hipLaunchKernelGGL(k_hp_pack, dim3(1024), dim3(256), 0, s, (const u32*)sc.hist, (const u32*)d_task_ids, (const u64*)d_ranges, d_tasks);
-    const u32 max_tasks = gaps / 17 + 1;
-    u32 grid = (max_tasks + (HP_BLOCK / 32) - 1) / (HP_BLOCK / 32);
-    if (grid > 2048u) grid = 2048u;
-    KernelScope ks(s, "k_hp_level");                  // all 62 launches are timed as one group
-    for (int level = 0; level < 62; ++level) {       // level = 63 - c0, c0 in [2, 63]
-        hipLaunchKernelGGL(k_hp_level, dim3(grid), dim3(HP_BLOCK), 0, s, (const u32*)sc.hist, level, (const uint4*)d_tasks,
-                           (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, d_cluster_idx, d_zero_parent, n);
-    }
+                       (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
 }
 
 } // namespace bvh

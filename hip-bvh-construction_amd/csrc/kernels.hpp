@@ -56,20 +56,26 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_sk
                         void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root);
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
-void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                  void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx /*u64[n] {id,rep}*/, uint64_t* d_ranges /*u64[n]*/,
-                  uint32_t* d_counter /*u32[n]*/, uint32_t* d_zero_parent /*u32[1]*/);
+// HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.
+struct HplocScratch {
+    void*     recs;          // 32-byte survivor records {id, rep, box} x n
+    uint64_t* dep;           // u64[n] dependency words {count:2 | R:30 | L:30}
+    uint32_t* zero_parent;   // u32[1]
+    uint32_t* queue_pc;      // u32[queue_capacity]   (block-local mode: nodes ready for k_hploc_ext)
+    uint64_t* queue_rng;     // u64[queue_capacity]
+    uint32_t* queue_count;   // u32[64 * 32]          (one padded head per sub-queue)
+    size_t    queue_capacity;
+};
+size_t hploc_queue_capacity(uint32_t n);
 uint32_t hploc_block_tile();
+void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+                  void* d_nodes, void* d_leaves, const HplocScratch& sc);
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_counter, uint32_t* d_zero_parent,
-                        uint32_t* d_queue /*u32[n]*/, uint32_t* d_queue_count /*u32[1]*/);
-void launch_hploc_levels(hipStream_t s, const SortScratch& sc, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
-                         void* d_nodes, void* d_leaves, uint64_t* d_cluster_idx, uint64_t* d_ranges, uint32_t* d_level_keys,
-                         uint32_t* d_task_keys, uint32_t* d_task_ids, uint4* d_tasks /*uint4[n/17+1]*/, uint32_t* d_zero_parent);
+                        void* d_nodes, void* d_leaves, const HplocScratch& sc);
 struct PlocScratch {
     void*     list0;         // 32-byte cluster entries {id, box} x n (ping)
     void*     list1;         // pong
-    uint32_t* ids1;          // u32[n] general scratch (HPLOC level mode: task ids)
+    uint32_t* ids1;          // u32[n]
     uint64_t* status;        // u64[PLOC_MAX_ITERS * chunks]
     uint32_t* state;         // u32[PLOC_STATE_WORDS]
 };

@@ -33,7 +33,7 @@ def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
     n = len(big)
     _, scene = orc.prim_bounds(big)
     hashes, sahs = [], []
-    for mode in ("levels", "async"):
+    for mode in ("block", "async"):
         os.environ["BVH_HPLOC_MODE"] = mode
         try:
             b = pkg.HPLOC().build(ctx, big)
@@ -46,7 +46,7 @@ def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
         s_cpu = orc.sah_bvh2(got["nodes"], got["leaves"], 0, n, 1)[0]
         assert abs(b.sah_cost() - s_cpu) <= 1e-9 * s_cpu
         sahs.append(s_cpu)
-    assert hashes[0] == hashes[1], "level-synchronous and asynchronous HPLOC schedulers must build the same tree"
+    assert hashes[0] == hashes[1], "block-local and asynchronous HPLOC schedulers must build the same tree"
 
 
 @pytest.mark.parametrize("algo", [1, 0])

@@ -209,11 +209,12 @@ def test_stage_level_emitters(pkg, orc, ctx, cases, name):
     assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_k.ptr, d_v.ptr, 5, 40) == -10001
 
 
-@pytest.mark.parametrize("mode", ["async", "levels"])
+@pytest.mark.parametrize("mode", ["async", "block"])
 def test_every_small_size(pkg, orc, ctx, mode, monkeypatch):
-    """n = 2..70 and a few sizes around the 16/32/64 thresholds, all four builders, both HPLOC schedulers"""
+    """n = 2..70 and a few sizes around the 16/32/64 thresholds and the block scheduler's 1024-leaf tile, all four builders, both
+    HPLOC schedulers (the block scheduler needs more than two tiles and hands smaller inputs to the asynchronous one)"""
     monkeypatch.setenv("BVH_HPLOC_MODE", mode)
-    for n in list(range(2, 71)) + [127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2049]:
+    for n in list(range(2, 71)) + [127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 2050, 3071, 3072, 3073, 4097]:
         tris = pkg.meshgen.uniform(n, 1000 + n)
         for algo in ((0, 1, 2, 3) if mode == "async" else (3,)):
             got = pkg.BUILDERS[algo]().build(ctx, tris).download(); ref = orc.build_tree(algo, tris)

@@ -11,7 +11,7 @@ import bvh_pkg
 import oracle as orc
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--modes", default="block,levels,async")
+ap.add_argument("--modes", default="block,async")
 ap.add_argument("--check", default="2100,3000,5000,20000,100000,262144")
 ap.add_argument("--time", default="262144,2000000,10000000")
 ap.add_argument("--reps", type=int, default=10)
