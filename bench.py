@@ -32,11 +32,9 @@ KERNEL_BYTES_PER_PRIM = {
     "k_morton": 32.0,             # R Aabb 24 + W key 4 + W val 4   (this build: 28, value is implicit)
     "k_onesweep": 17.0,           # per pass: R 8 + W 8 (+ hist R 4 amortised over 4 passes)
     "k_ploc_setup": 88.0,         # SetupClusters for PLOC++: R val 4 + gather Aabb 24 + W PrimRef 28 + W list entry 32
-    "k_hploc": 134.0,             # keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32
-    "k_hp_level": 114.0,          # level-synchronous variant, all 62 level launches as one group: the same minus keys (4, read by
-                                  # k_hp_plan) and the parent exchange (16, replaced by launch order)
-    "k_hp_plan": 8.7,             # R key 4 + W level key 4 + W range 8 per big node (~0.09 / prim)
-    "k_hist": 4.0,
+    "k_hploc": 198.0,             # one-launch HPLOC (n < 1 M): SetupClusters 64 + HPloc 134 (keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32)
+    "k_hploc_block": 177.9,       # block-local kernel: SetupClusters 64 + 85 % of HPloc's 134 (the merge tasks whose range lies inside a 512-leaf tile)
+    "k_hploc_ext": 20.1,          # the other 15 % of the merge tasks (ranges crossing tiles)
     "k_lbvh_single": 224.0,
     "k_karras": 100.0, "k_refit": 88.0,
     "k_ploc_iter": 190.0,         # summed over all iterations

@@ -17,7 +17,7 @@
 //    two halves.  No barriers inside a task, no reliance on store conflict order.
 //  * large inputs (k_hploc_block): a workgroup owns a tile of T consecutive sorted leaves and processes every node whose
 //    range lies inside the tile out of LDS, level by level; only the nodes that cross tile boundaries (the ancestors of the
-//    T-aligned gaps, ~9 % of the tasks at T = 1024) use the inter-workgroup protocol below, in a second launch (k_hploc_ext).
+//    T-aligned gaps, ~15 % of the tasks at T = 512) use the inter-workgroup protocol below, in a second launch (k_hploc_ext).
 //    Small inputs (k_hploc): one launch, every big node uses the protocol.
 //  * inter-workgroup protocol: ONE 64-bit word per node, dep[p] = {count:2 | R:30 | L:30}.  Only "big" nodes (range > 16)
 //    take part.  A finished left child adds {1, 0, its L}, a finished right child {1, its R, 0}; the node's own thread adds
@@ -58,6 +58,10 @@ __device__ __forceinline__ Box box_shl1(const Box& b) { return { dpp_shl1(b.lx),
 __device__ __forceinline__ Box shfl_box(const Box& b, int src) {
     return { __shfl(b.lx, src), __shfl(b.ly, src), __shfl(b.lz, src), __shfl(b.hx, src), __shfl(b.hy, src), __shfl(b.hz, src) };
 }
+__device__ __forceinline__ float bperm_f32(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+#ifndef HP_DPP_R
+#define HP_DPP_R 8
+#endif
 // push semantics: lane l's value lands in lane dst(l)
 __device__ __forceinline__ u32 push_u32(int dst, u32 v) { return (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)v); }
 __device__ __forceinline__ float push_f32(int dst, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v))); }
@@ -132,12 +136,18 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
             // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
             u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
+            // neighbour fetches: ds_bpermute with the lane distance in the instruction's immediate offset (byte address
+            // lane*4 + 4r, wraps modulo the wave) — no address arithmetic; radii up to HP_DPP_R come from a DPP shift chain
+            // instead (VALU moves), the rest from the LDS crossbar: the split balances the two pipes
+            const int la = lane << 2;
             Box nb = b;
 #pragma unroll
             for (int r = 1; r <= HP_RADIUS; ++r) {
-                nb = box_shl1(nb);                                               // box of slot + r
+                if (r <= HP_DPP_R) nb = box_shl1(nb);                            // box of slot + r
+                else nb = { bperm_f32(la + 4 * r, b.lx), bperm_f32(la + 4 * r, b.ly), bperm_f32(la + 4 * r, b.lz),
+                            bperm_f32(la + 4 * r, b.hx), bperm_f32(la + 4 * r, b.hy), bperm_f32(la + 4 * r, b.hz) };
                 const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
-                const u32 ab_left = (u32)__shfl_up((int)ab, r);                  // area(slot - r, slot)
+                const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * r), (int)ab);   // area(slot - r, slot)
                 if ((u32)(slot + r) < cnt && ab < abR) { abR = ab; idR = slot + r; }
                 if (slot >= r && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - r; }
             }
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                     u32 L, R;
                     if (dep_arrive(dep, pc, dep_word(3u - e, lbig ? 0u : (u32)lo, rbig ? 0u : (u32)hi), L, R)) ready_push(pc, L, R);
                 }
-            } else if (my_lv[i] >= 0) {
+            } else if (m_range[k] != 0u) {           // local big node
                 const u32 rg = m_range[k];
                 const u32 L = g0 + (rg & 0xFFFFu), R = g0 + (rg >> 16);
                 const u32 q = parent_gap(L, R, ni, [&](u32 j) { return wkey((int)j); });
@@ -536,15 +546,16 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, c
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
 }
 
-// Block-local HPLOC for large n (n > 2 tiles: the root is never local).
+// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  Tile 512 leaves / 256 threads / 7 waves per SIMD
+// (72 VGPRs, no spills; 8 waves spill into scratch) measured best on MI355X: 10 M emit 1.10 ms vs 1.16 (1024/512/6) and 1.24 (256/128).
 #ifndef HPB_T
-#define HPB_T 1024
+#define HPB_T 512
 #endif
 #ifndef HPB_NT
-#define HPB_NT 512
+#define HPB_NT 256
 #endif
 #ifndef HPB_OCC
-#define HPB_OCC 8
+#define HPB_OCC 7
 #endif
 static void hpb_config(int* t, int* nt, int* occ) {
     *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
@@ -564,11 +575,9 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_sk
 #define HPB_LAUNCH(TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, \
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg)
     { KernelScope ks(s, "k_hploc_block");
-      if (t == 512 && nt == 256 && occ == 8) HPB_LAUNCH(512, 256, 8);
-      else if (t == 256 && nt == 128 && occ == 8) HPB_LAUNCH(256, 128, 8);
-      else if (t == 2048 && nt == 1024 && occ == 8) HPB_LAUNCH(2048, 1024, 8);
-      else if (occ == 1) HPB_LAUNCH(1024, 512, 1);
-      else HPB_LAUNCH(1024, 512, 8); }
+      if (t == 1024 && nt == 512) HPB_LAUNCH(1024, 512, 6);
+      else if (t == 256 && nt == 128) HPB_LAUNCH(256, 128, 7);
+      else HPB_LAUNCH(HPB_T, HPB_NT, HPB_OCC); }
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
