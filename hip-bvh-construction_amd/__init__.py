@@ -59,7 +59,8 @@ ALGO_NAMES = {0: "TwoPassLbvh", 1: "SinglePassLbvh", 2: "PLOCNew", 3: "HPLOC"}
 # every symbol include/bvh_mi355x.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
-    "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_stage_extents", "bvh_stage_morton", "bvh_sort_pairs",
+    "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_build_ex", "bvh_stage_extents", "bvh_stage_extents_ex",
+    "bvh_stage_morton", "bvh_stage_morton64", "bvh_sort_pairs", "bvh_sort_pairs64",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_sah_cost",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
@@ -78,7 +79,16 @@ class Timings(C.Structure):
 class Result(C.Structure):
     _fields_ = [("d_nodes", C.c_void_p), ("d_leaves", C.c_void_p), ("d_prim_aabbs", C.c_void_p), ("d_scene_extent", C.c_void_p),
                 ("d_sorted_keys", C.c_void_p), ("d_sorted_vals", C.c_void_p), ("root", C.c_uint32), ("n_internal", C.c_uint32),
-                ("n_leaves", C.c_uint32), ("layout", C.c_uint32)]
+                ("n_leaves", C.c_uint32), ("layout", C.c_uint32), ("key_bits", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+TRI_PADDED64, TRI_PACKED36, TRI_INDEXED = 0, 1, 2
+
+
+class BuildInput(C.Structure):
+    """bvh_build_input: device pointers; tri_format TRI_*, morton_bits 30 / 60"""
+    _fields_ = [("tri_format", C.c_uint32), ("morton_bits", C.c_uint32), ("d_tris", C.c_void_p), ("d_vertices", C.c_void_p),
+                ("d_indices", C.c_void_p), ("n_vertices", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def build_native(verbose: bool = False) -> str:
@@ -111,6 +121,10 @@ def lib() -> C.CDLL:
         "bvh_ctx_destroy": ([vp], None), "bvh_ctx_reserve": ([vp, u32], i32), "bvh_ctx_device": ([vp], i32),
         "bvh_ctx_stream": ([vp], vp), "bvh_ctx_set_profiling": ([vp, i32], i32), "bvh_ctx_synchronize": ([vp], i32),
         "bvh_build": ([vp, i32, vp, u32, i32, C.POINTER(Result), C.POINTER(Timings)], i32),
+        "bvh_build_ex": ([vp, i32, C.POINTER(BuildInput), u32, C.POINTER(Result), C.POINTER(Timings)], i32),
+        "bvh_stage_extents_ex": ([vp, C.POINTER(BuildInput), u32, vp, vp], i32),
+        "bvh_stage_morton64": ([vp, vp, u32, vp, vp, i32], i32),
+        "bvh_sort_pairs64": ([vp, vp, vp, u32, vp, vp, i32, i32], i32),
         "bvh_stage_extents": ([vp, vp, u32, vp, vp], i32), "bvh_stage_morton": ([vp, vp, u32, vp, vp, vp], i32),
         "bvh_sort_pairs": ([vp, vp, vp, u32, vp, vp, i32, i32], i32),
         "bvh_emit_lbvh_single": ([vp, vp, vp, vp, u32, vp, C.POINTER(u32)], i32),
@@ -265,6 +279,18 @@ class _Builder:
         self._ctx = context
         _check(lib().bvh_build(context.handle, self.ALGO, _ptr(primitives), n, int(on_device), C.byref(self.result), C.byref(self.timings)),
                f"{ALGO_NAMES[self.ALGO]}::build")
+        return self._publish()
+
+    def build_ex(self, context: Context, n: int, tris=None, vertices=None, indices=None, n_vertices: int = 0, tri_format: int = TRI_PADDED64,
+                 morton_bits: int = 30) -> "_Builder":
+        """bvh_build_ex: device inputs in any bvh_tri_format, 30- or 60-bit Morton codes."""
+        self._ctx = context
+        inp = BuildInput(tri_format, morton_bits, _ptr(tris) if tris is not None else None, _ptr(vertices) if vertices is not None else None,
+                         _ptr(indices) if indices is not None else None, n_vertices, 0)
+        _check(lib().bvh_build_ex(context.handle, self.ALGO, C.byref(inp), n, C.byref(self.result), C.byref(self.timings)), f"{ALGO_NAMES[self.ALGO]}::build_ex")
+        return self._publish()
+
+    def _publish(self) -> "_Builder":
         r, t = self.result, self.timings
         self.m_rootNodeIdx, self.m_nInternalNodes = r.root, r.n_internal
         self.d_bvhNodes, self.d_leafNodes = r.d_nodes, r.d_leaves
@@ -281,7 +307,7 @@ class _Builder:
         n = r.n_leaves
         nodes = np.empty(2 * n - 1 if r.layout == 0 else n - 1, dtype=BVH2_NODE)
         leaves = np.empty(n, dtype=PRIMREF) if r.layout == 1 else None
-        keys = np.empty(n, dtype=np.uint32); vals = np.empty(n, dtype=np.uint32); scene = np.empty(1, dtype=AABB)
+        keys = np.empty(n, dtype=np.uint64 if r.key_bits == 64 else np.uint32); vals = np.empty(n, dtype=np.uint32); scene = np.empty(1, dtype=AABB)
         _check(lib().bvh_download(self._ctx.handle, C.byref(r), nodes.ctypes.data, leaves.ctypes.data if leaves is not None else None,
                                   keys.ctypes.data, vals.ctypes.data, scene.ctypes.data), "bvh_download")
         return {"nodes": nodes, "leaves": leaves, "sorted_keys": keys, "sorted_vals": vals, "scene": scene, "root": r.root, "layout": r.layout}

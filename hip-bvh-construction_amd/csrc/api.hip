@@ -43,7 +43,7 @@ struct bvh_ctx {
     uint32_t tris_cap = 0;
     bvh_aabb* boxes = nullptr;
     float* scene = nullptr;
-    u32 *keys = nullptr, *skeys = nullptr, *svals = nullptr;
+    u32 *keys = nullptr, *skeys = nullptr, *svals = nullptr;   // keys / skeys: 8 bytes per primitive (u32 keys use the first half)
     SortScratch sort{};
     bvh2_node* nodes = nullptr;       // 2*cap
     bvh_primref* leaves = nullptr;    // cap
@@ -69,9 +69,9 @@ inline bool hploc_use_block(uint32_t n) {
     return n >= HPLOC_BLOCK_MIN_N;
 }
 // HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
-void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const u32* d_skeys, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves) {
-    if (hploc_use_block(n)) launch_hploc_block(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->hploc);
-    else launch_hploc(s, d_boxes, d_skeys, d_svals, n, d_nodes, d_leaves, c->hploc);
+void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves) {
+    if (hploc_use_block(n)) launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc);
+    else launch_hploc(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc);
 }
 
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
@@ -89,8 +89,8 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     const size_t n = cap;
     c->boxes = k.take<bvh_aabb>(n);
     c->scene = k.take<float>(8);
-    c->keys = k.take<u32>(n); c->skeys = k.take<u32>(n); c->svals = k.take<u32>(n);
-    c->sort.pairs0 = k.take<u64>(n); c->sort.pairs1 = k.take<u64>(n);
+    c->keys = reinterpret_cast<u32*>(k.take<u64>(n)); c->skeys = reinterpret_cast<u32*>(k.take<u64>(n)); c->svals = k.take<u32>(n);
+    c->sort.pairs0 = k.take<uint4>(n); c->sort.pairs1 = k.take<uint4>(n);
     c->sort.hist = k.take<u32>(SORT_MAX_PASSES * SORT_RADIX);
     c->sort.status = k.take<u32>(sort_status_bytes(cap) / sizeof(u32));
     c->sort.counters = k.take<u32>(SORT_MAX_PASSES);
@@ -167,6 +167,18 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, const void* d_leaves, const 
         first += batch; batch = 16;
     }
     return BVH_E_INTERNAL;
+}
+
+// stage E on any of the input formats of bvh_build_input (device pointers)
+int stage_extents_fmt(hipStream_t s, const bvh_build_input* in, uint32_t n, void* d_boxes, void* d_scene) {
+    switch (in->tri_format) {
+        case BVH_TRI_PADDED64: if (!in->d_tris) return BVH_E_INVALID_ARG; launch_extents(s, in->d_tris, n, d_boxes, d_scene); return 0;
+        case BVH_TRI_PACKED36: if (!in->d_tris || ((uintptr_t)in->d_tris & 15u)) return BVH_E_INVALID_ARG;      // 16-byte loads
+                               launch_extents_packed(s, in->d_tris, n, d_boxes, d_scene); return 0;
+        case BVH_TRI_INDEXED:  if (!in->d_vertices || !in->d_indices || in->n_vertices == 0) return BVH_E_INVALID_ARG;
+                               launch_extents_indexed(s, in->d_vertices, in->d_indices, in->n_vertices, n, d_boxes, d_scene); return 0;
+        default: return BVH_E_INVALID_ARG;
+    }
 }
 
 // per-primitive algorithmic bytes of the whole pipeline (restated in DESIGN.md)
@@ -261,8 +273,33 @@ int bvh_sort_pairs(bvh_ctx* c, const uint32_t* d_keys_in, const uint32_t* d_vals
     if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    sort_prepare(c->stream, c->sort, n);
+    sort_prepare(c->stream, c->sort, n, sort_passes(start_bit, end_bit));
     sort_pairs(c->stream, c->sort, d_keys_in, d_vals_in, n, d_keys_out, d_vals_out, start_bit, end_bit, false);
+    return herr(hipGetLastError());
+}
+
+int bvh_sort_pairs64(bvh_ctx* c, const uint64_t* d_keys_in, const uint32_t* d_vals_in, uint32_t n, uint64_t* d_keys_out,
+                     uint32_t* d_vals_out, int start_bit, int end_bit) {
+    if (!c || !d_keys_in || !d_keys_out || !d_vals_out || n == 0 || start_bit < 0 || end_bit > 64 || start_bit > end_bit) return BVH_E_INVALID_ARG;
+    if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    sort_prepare(c->stream, c->sort, n, sort_passes(start_bit, end_bit));
+    sort_pairs64(c->stream, c->sort, d_keys_in, d_vals_in, n, d_keys_out, d_vals_out, start_bit, end_bit, false);
+    return herr(hipGetLastError());
+}
+
+int bvh_stage_morton64(bvh_ctx* c, const void* d_prim_aabbs, uint32_t n, const void* d_scene_extent, uint64_t* d_keys, int total_bits) {
+    if (!c || !d_prim_aabbs || !d_scene_extent || !d_keys || n == 0 || total_bits < 3 || total_bits > 60) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    launch_morton64(c->stream, d_prim_aabbs, n, d_scene_extent, d_keys, total_bits, nullptr, 0);
+    return herr(hipGetLastError());
+}
+
+int bvh_stage_extents_ex(bvh_ctx* c, const bvh_build_input* in, uint32_t n, void* d_prim_aabbs, void* d_scene_extent) {
+    if (!c || !in || !d_prim_aabbs || !d_scene_extent || n == 0) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = stage_extents_fmt(c->stream, in, n, d_prim_aabbs, d_scene_extent); if (r) return r;
     return herr(hipGetLastError());
 }
 
@@ -271,7 +308,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, c->slots, c->small);
+    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->slots, c->small);
     HIP_TRY(hipGetLastError());
     if (root_out) { HIP_TRY(hipMemcpyAsync(root_out, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return 0;
@@ -282,7 +319,7 @@ int bvh_emit_lbvh_two(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_so
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, c->parent, c->flags);
+    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags);
     return herr(hipGetLastError());
 }
 
@@ -301,44 +338,39 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    emit_hploc(c, c->stream, d_prim_aabbs, d_sorted_keys, d_sorted_vals, n, d_nodes, d_leaves);
+    emit_hploc(c, c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, d_leaves);
     return herr(hipGetLastError());
 }
 
-int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_on_device, bvh_result* out, bvh_timings* tm) {
-    if (!c || !tris || !out || n < 2 || (int)algo < 0 || (int)algo > 3) return BVH_E_INVALID_ARG;
-    if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
-    Bind b(c->device);
-    int r = ensure_capacity(c, n); if (r) return r;
-    const void* d_tris = tris;
-    if (!tris_on_device) {   // H2D copy of the input, outside the timers (src/TwoPassLbvh.cpp:19-20)
-        r = ensure_tris(c, n); if (r) return r;
-        HIP_TRY(hipMemcpyAsync(c->tris, tris, (size_t)n * sizeof(bvh_triangle), hipMemcpyHostToDevice, c->stream));
-        d_tris = c->tris;
-    }
+static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* tm) {
+    const int key_bits = in->morton_bits == 60 ? 64 : 32;
     hipStream_t s = c->stream;
     const bool prof = c->profiling;
     struct Install { bool on; explicit Install(bvh_ctx* c) : on(c->kernel_profiling) { if (on) g_recorder = &c->recorder; } ~Install() { if (on) g_recorder = nullptr; } } install(c);
     uint32_t ploc_iters = 0;
+    int r = 0;
     if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
     // E: CalculateSceneExtents (token CalculateCentroidExtentsTime).  The sort's bookkeeping is cleared here so that the
     // Morton kernel can accumulate the digit histograms.
-    sort_prepare(s, c->sort, n);
-    launch_extents(s, d_tris, n, c->boxes, c->scene);
+    const int end_bit = key_bits == 64 ? 60 : 30;              // significant bits of the Morton codes
+    const int passes = sort_passes(0, end_bit);
+    sort_prepare(s, c->sort, n, passes);
+    r = stage_extents_fmt(s, in, n, c->boxes, c->scene); if (r) return r;
     if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
     // M: CalculateMortonCodes (token CalculateMortonCodesTime); values are implicit (value i = i), produced by sort pass 0
-    const int end_bit = 30;
-    launch_morton(s, c->boxes, n, c->scene, c->keys, nullptr, c->sort.hist, SORT_BITS, sort_passes(0, end_bit));
+    if (key_bits == 64) launch_morton64(s, c->boxes, n, c->scene, reinterpret_cast<u64*>(c->keys), 60, c->sort.hist, passes);
+    else launch_morton(s, c->boxes, n, c->scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes);
     if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
-    // S: radix sort (token SortingTime).  Morton codes have 30 significant bits.
-    sort_pairs(s, c->sort, c->keys, nullptr, n, c->skeys, c->svals, 0, end_bit, true);
+    // S: radix sort (token SortingTime)
+    if (key_bits == 64) sort_pairs64(s, c->sort, reinterpret_cast<const u64*>(c->keys), nullptr, n, reinterpret_cast<u64*>(c->skeys), c->svals, 0, end_bit, true);
+    else sort_pairs(s, c->sort, c->keys, nullptr, n, c->skeys, c->svals, 0, end_bit, true);
     if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
     // B: hierarchy emit (token BvhBuildTime; SetupClusters is booked here, not under Morton as the reference does)
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
     switch (algo) {
-        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->slots, c->small); break;
-        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, c->svals, n, c->nodes, c->parent, c->flags); break;
-        case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, c->svals, n, c->nodes, c->leaves);
+        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->slots, c->small); break;
+        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags); break;
+        case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);
                                   r = run_ploc(c, n, c->nodes, c->leaves, c->ploc, &ploc_iters); if (r) return r;
@@ -353,7 +385,7 @@ int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_
     }
     out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = c->scene;
     out->d_sorted_keys = c->skeys; out->d_sorted_vals = c->svals;
-    out->n_internal = n - 1; out->n_leaves = n;
+    out->n_internal = n - 1; out->n_leaves = n; out->key_bits = (uint32_t)key_bits; out->reserved = 0;
     if (tm) {
         std::memset(tm, 0, sizeof *tm);
         tm->bytes_algorithmic = algorithmic_bytes(algo, n);
@@ -368,6 +400,30 @@ int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_
         }
     }
     return 0;
+}
+
+int bvh_build(bvh_ctx* c, bvh_algo algo, const void* tris, uint32_t n, int tris_on_device, bvh_result* out, bvh_timings* tm) {
+    if (!c || !tris || !out || n < 2 || (int)algo < 0 || (int)algo > 3) return BVH_E_INVALID_ARG;
+    if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    bvh_build_input in; std::memset(&in, 0, sizeof in);
+    in.tri_format = BVH_TRI_PADDED64; in.morton_bits = 30; in.d_tris = tris;
+    if (!tris_on_device) {   // H2D copy of the input, outside the timers (src/TwoPassLbvh.cpp:19-20)
+        r = ensure_tris(c, n); if (r) return r;
+        HIP_TRY(hipMemcpyAsync(c->tris, tris, (size_t)n * sizeof(bvh_triangle), hipMemcpyHostToDevice, c->stream));
+        in.d_tris = c->tris;
+    }
+    return build_impl(c, algo, &in, n, out, tm);
+}
+
+int bvh_build_ex(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* tm) {
+    if (!c || !in || !out || n < 2 || (int)algo < 0 || (int)algo > 3) return BVH_E_INVALID_ARG;
+    if (in->morton_bits != 30 && in->morton_bits != 60) return BVH_E_INVALID_ARG;
+    if (n >= (1u << 30)) return BVH_E_TOO_LARGE;
+    Bind b(c->device);
+    int r = ensure_capacity(c, n); if (r) return r;
+    return build_impl(c, algo, in, n, out, tm);
 }
 
 int bvh_to_lbvh_layout(bvh_ctx* c, const bvh_result* in, void* d_out) {
@@ -434,14 +490,14 @@ int bvh_sah_cost(bvh_ctx* c, const bvh_result* in, double* cost_out) {
     return herr(hipStreamSynchronize(c->stream));
 }
 
-int bvh_download(bvh_ctx* c, const bvh_result* in, void* h_nodes, void* h_leaves, uint32_t* h_sorted_keys, uint32_t* h_sorted_vals, void* h_scene) {
+int bvh_download(bvh_ctx* c, const bvh_result* in, void* h_nodes, void* h_leaves, void* h_sorted_keys, uint32_t* h_sorted_vals, void* h_scene) {
     if (!c || !in) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     const size_t n = in->n_leaves;
     const size_t node_count = in->layout == 0 ? 2 * n - 1 : n - 1;
     if (h_nodes) HIP_TRY(hipMemcpyAsync(h_nodes, in->d_nodes, node_count * sizeof(bvh2_node), hipMemcpyDeviceToHost, c->stream));
     if (h_leaves && in->d_leaves) HIP_TRY(hipMemcpyAsync(h_leaves, in->d_leaves, n * sizeof(bvh_primref), hipMemcpyDeviceToHost, c->stream));
-    if (h_sorted_keys) HIP_TRY(hipMemcpyAsync(h_sorted_keys, in->d_sorted_keys, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_sorted_keys) HIP_TRY(hipMemcpyAsync(h_sorted_keys, in->d_sorted_keys, n * (in->key_bits == 64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
     if (h_sorted_vals) HIP_TRY(hipMemcpyAsync(h_sorted_vals, in->d_sorted_vals, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (h_scene) HIP_TRY(hipMemcpyAsync(h_scene, in->d_scene_extent, sizeof(bvh_aabb), hipMemcpyDeviceToHost, c->stream));
     return herr(hipStreamSynchronize(c->stream));

@@ -128,4 +128,21 @@ __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull
 // 64-bit augmented key of sorted position i (Morton key in the high word, position in the low word)
 __device__ __forceinline__ u64 aug_key(const u32* __restrict__ keys, u32 i) { return ((u64)keys[i] << 32) | i; }
 
+// ---- key arithmetic of the hierarchy emitters, for 30-bit keys (u32, the reference) and 60-bit keys (u64).
+// The emitters only ever ask (1) how many leading bits the augmented keys {Morton key, sorted position} of two positions
+// share — plen, in [0, 32 + bits of K) — and (2) which of two adjacent pairs is closer.  For u32 keys the augmented key is one
+// 64-bit word and "closer" is the reference's comparison of the xor values (src/SinglePassLbvhKernel.h:56-62,73); for u64 keys
+// the augmented key has 96 bits and "closer" compares prefix lengths, which is the same order for the two boundary gaps of a
+// range (they can never have equal prefix lengths: the keys inside the range share a strictly longer prefix than either).
+__device__ __forceinline__ int clz_u64(u64 v) { return v ? __clzll((long long)v) : 64; }
+__device__ __forceinline__ int clz_u32(u32 v) { return v ? __clz((int)v) : 32; }
+__device__ __forceinline__ int plen(u32 ka, u32 i, u32 kb, u32 j) { return clz_u64((((u64)ka << 32) | i) ^ (((u64)kb << 32) | j)); }
+__device__ __forceinline__ int plen(u64 ka, u32 i, u64 kb, u32 j) { return ka != kb ? clz_u64(ka ^ kb) : 64 + clz_u32(i ^ j); }
+template <typename K> struct KeyBits;
+template <> struct KeyBits<u32> { static constexpr int value = 64; };    // bits of the augmented key = number of hierarchy levels
+template <> struct KeyBits<u64> { static constexpr int value = 96; };
+// is the pair (a, a+1) closer than the pair (b, b+1)?  (both pairs adjacent sorted positions)
+__device__ __forceinline__ bool closer(const u32* __restrict__ k, u32 a, u32 b) { return (aug_key(k, a) ^ aug_key(k, a + 1)) < (aug_key(k, b) ^ aug_key(k, b + 1)); }
+__device__ __forceinline__ bool closer(const u64* __restrict__ k, u32 a, u32 b) { return plen(k[a], a, k[a + 1], a + 1) > plen(k[b], b, k[b + 1], b + 1); }
+
 } // namespace bvh

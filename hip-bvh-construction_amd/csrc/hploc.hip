@@ -79,11 +79,11 @@ __device__ __forceinline__ bool dep_arrive(u64* dep, u32 q, u64 mine, u32& L, u3
 }
 
 // findParent (:66-81): the boundary gap with the longer common prefix (smaller xor) is the parent of range [L,R] (not the root)
-template <typename KeyAt>
-__device__ __forceinline__ u32 parent_gap(u32 L, u32 R, u32 ni, KeyAt key_at) {
+template <typename Closer>
+__device__ __forceinline__ u32 parent_gap(u32 L, u32 R, u32 ni, Closer pair_closer) {   // pair_closer(a, b): is (a, a+1) closer than (b, b+1)?
     if (L == 0u) return R;
     if (R == ni) return L - 1u;
-    return ((key_at(R) ^ key_at(R + 1u)) < (key_at(L - 1u) ^ key_at(L))) ? R : L - 1u;
+    return pair_closer(R, L - 1u) ? R : L - 1u;
 }
 
 struct HpWork { u32 id, rep, cnt, tL; Box b; bool have, final_; };
@@ -200,8 +200,8 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
 
 // ---- the asynchronous part: run ready merge tasks, two per pass (one per 32-lane half of the wave), then hand the finished
 // range to the parent node (dep_arrive); a lane that completes its parent runs it next.  No waiting anywhere.
-template <bool SETUP>
-__device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+template <bool SETUP, typename K>
+__device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                             const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs,
                                             u64* dep, u32* zero_parent, u32 ni, int lane) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
@@ -218,7 +218,7 @@ __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, co
         // the owners look up their parent now: the four key loads fly while the task runs
         const bool owner = ready && (lane == ownA || lane == ownB);
         u32 q = INV;
-        if (owner && !(L == 0u && R == ni)) q = parent_gap(L, R, ni, [&](u32 j) { return aug_key(skeys, j); });
+        if (owner && !(L == 0u && R == ni)) q = parent_gap(L, R, ni, [&](u32 a, u32 b) { return closer(skeys, a, b); });
 
         HpWork w = load_work<SETUP>(have, tL, tR, tP, boxes, svals, leaves, recs, ni, slot, hbase);
         ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase);
@@ -237,7 +237,8 @@ __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, co
 }
 
 // Small inputs: one launch.  Phase 1: range of every gap from the keys; big nodes enter the dependency protocol.  Phase 2: climb.
-__global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+template <typename K>
+__global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* leaves,
                                                     bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 n, int dbg) {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -248,20 +249,17 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__
 
     // The block's key window [g0 - 256, g0 + 512] sits in LDS: almost every probe of the common-prefix searches lands there
     // (a dependent L2 round trip per probe otherwise); only ranges reaching beyond the window probe global memory.
-    __shared__ u32 s_keys[HP_BLOCK * 3 + 1];
+    __shared__ K s_keys[HP_BLOCK * 3 + 1];
     const int g0 = (int)(blockIdx.x * HP_BLOCK);
     const int w0 = g0 - HP_BLOCK;
-    for (int k = threadIdx.x; k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : 0u; }
+    for (int k = threadIdx.x; k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : (K)0; }
     __syncthreads();
-    auto key_at = [&](int j) -> u64 {
-        const u32 k = ((u32)(j - w0) <= (u32)(HP_BLOCK * 3)) ? s_keys[j - w0] : skeys[j];
-        return ((u64)k << 32) | (u32)j;
-    };
+    auto key_at = [&](int j) -> K { return ((u32)(j - w0) <= (u32)(HP_BLOCK * 3)) ? s_keys[j - w0] : skeys[j]; };
     if (pc < ni) {
         const int p = (int)pc;
-        const u64 kp = key_at(p);
-        const int c0 = clz64(kp ^ key_at(p + 1));                               // common prefix length of the node
-        auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(key_at(j) ^ kp) >= c0; };
+        const K kp = key_at(p);
+        const int c0 = plen(kp, (u32)p, key_at(p + 1), (u32)p + 1u);             // common prefix length of the node
+        auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && plen(key_at(j), (u32)j, kp, (u32)p) >= c0; };
         {   // leftmost leaf sharing the prefix (n < 2^30: int arithmetic cannot overflow)
             int step = 1;
             while (inside(p - step)) step <<= 1;
@@ -309,22 +307,23 @@ __device__ __forceinline__ void queue_put(u32* q_pc, u64* q_rng, u32 q_cap, u32 
     q_pc[at] = pc; q_rng[at] = (u64)L | ((u64)R << 32);
 }
 
-template <int T, int NT, int OCC>
-__global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+template <typename K, int T, int NT, int OCC>
+__global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
                                                     bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent,
                                                     u32* q_pc, u64* q_rng, u32* q_count, u32 q_cap, u32 n, int dbg) {
     constexpr int PER = T / NT;                      // leaf positions (and gaps) per thread
     constexpr int NW = NT / WAVE;
     static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
-    __shared__ u32 s_key[T + 2];                     // sorted keys of positions g0-1 .. g0+T
+    constexpr int NLEV = KeyBits<K>::value;          // hierarchy levels = bits of the augmented key (64 / 96)
+    __shared__ K s_key[T + 2];                       // sorted keys of positions g0-1 .. g0+T
     // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
     // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
     __shared__ unsigned short e_id[T], e_rep[T];     // id: 0x8000 | k = leaf ni + g0 + k;  k = node g0 + k;  0xFFFF = invalid
     __shared__ float e_b[6][T];
     __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
-    __shared__ u32 s_cnt[64], s_off[64];
+    __shared__ u32 s_cnt[128], s_off[128];
     __shared__ u32 s_npub, s_nready, s_qbase;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
 
@@ -350,8 +349,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             e_b[0][k] = b.lx; e_b[1][k] = b.ly; e_b[2][k] = b.lz; e_b[3][k] = b.hx; e_b[4][k] = b.hy; e_b[5][k] = b.hz;
         }
     }
-    for (int k = tid; k < T + 2; k += NT) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : 0u; }
-    if (tid < 64) s_cnt[tid] = 0u;
+    for (int k = tid; k < T + 2; k += NT) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
+    if (tid < 128) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; }
     __syncthreads();
     if (dbg == 1) return;
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     constexpr u32 M_EXT = 0xFFFFFFFFu;
     const int jmin = g0 ? (int)g0 - 1 : 0;
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
-    auto wkey = [&](int j) -> u64 { return ((u64)s_key[j - (int)g0 + 1] << 32) | (u32)j; };
+    auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + 1]; };
     int my_lv[PER]; u32 my_pos[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -369,9 +368,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         my_lv[i] = -1; my_pos[i] = 0;
         if (k < nleaf && pc < ni) {
             const int p = (int)pc;
-            const u64 kp = wkey(p);
-            const int c0 = clz64(kp ^ wkey(p + 1));
-            auto inside = [&](int j) -> bool { return j >= jmin && j <= jmax && clz64(wkey(j) ^ kp) >= c0; };
+            const K kp = wkey(p);
+            const int c0 = plen(kp, (u32)p, wkey(p + 1), (u32)p + 1u);
+            auto inside = [&](int j) -> bool { return j >= jmin && j <= jmax && plen(wkey(j), (u32)j, kp, (u32)p) >= c0; };
             int step = 1;
             while (inside(p - step)) step <<= 1;
             int lo = p - (step >> 1);
@@ -384,17 +383,17 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             m_range[k] = ext ? M_EXT : 0u;
             if (!ext && (u32)(hi - lo + 1) > HP_HALF) {
                 m_range[k] = (u32)(lo - (int)g0) | ((u32)(hi - (int)g0) << 16);
-                my_lv[i] = 63 - c0;
+                my_lv[i] = NLEV - 1 - c0;
                 my_pos[i] = atomicAdd(&s_cnt[my_lv[i]], 1u);
             }
         }
     }
     __syncthreads();
-    if (tid < 64) {                                  // exclusive scan of the level counts
-        const u32 v = s_cnt[tid]; u32 incl = v;
+    if (tid < 64) {                                  // exclusive scan of the (<= 128) level counts, two per lane
+        const u32 v0 = s_cnt[2 * tid], v1 = s_cnt[2 * tid + 1]; u32 incl = v0 + v1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
-        s_off[tid] = incl - v;
+        s_off[2 * tid] = incl - v0 - v1; s_off[2 * tid + 1] = incl - v1;
     }
     __syncthreads();
 #pragma unroll
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     if (dbg == 2) return;
 
     // ---- local hierarchy, deepest level first; two tasks per wave pass ----------------------------------------------------
-    for (int lv = 0; lv < 62; ++lv) {
+    for (int lv = 0; lv < NLEV; ++lv) {
         const u32 c = s_cnt[lv];
         if (!c) continue;                            // block-uniform
         const u32 base = s_off[lv];
@@ -444,10 +443,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     // those children's far ends (child [L,p] is big iff leaf p-16 shares the prefix, child [p+1,R] iff leaf p+17 does);
     // a maximal local node (parent external) is listed for publication.  (s_task is dead as a task list: every thread is past
     // the level loop's last barrier.)
-    auto gkey = [&](int j) -> u64 {
-        const u32 kv = (j >= jmin && j <= jmax) ? s_key[j - (int)g0 + 1] : skeys[j];
-        return ((u64)kv << 32) | (u32)j;
-    };
+    auto gkey = [&](int j) -> K { return (j >= jmin && j <= jmax) ? s_key[j - (int)g0 + 1] : skeys[j]; };
     auto ready_push = [&](u32 pc, u32 L, u32 R) {
         const u32 at = atomicAdd(&s_nready, 1u);
         if (at < HPQ_LOCAL) { r_pc[at] = pc; r_L[at] = L; r_R[at] = R; }
@@ -460,9 +456,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         if (k < nleaf && pc < ni) {
             if (m_range[k] == M_EXT) {
                 const int p = (int)pc;
-                const u64 kp = gkey(p);
-                const int c0 = clz64(kp ^ gkey(p + 1));
-                auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && clz64(gkey(j) ^ kp) >= c0; };
+                const K kp = gkey(p);
+                const int c0 = plen(kp, (u32)p, gkey(p + 1), (u32)p + 1u);
+                auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && plen(gkey(j), (u32)j, kp, (u32)p) >= c0; };
                 const bool lbig = inside(p - (int)HP_HALF), rbig = inside(p + 1 + (int)HP_HALF);
                 int lo = p, hi = p + 1;
                 if (!lbig) { for (int t = 8; t > 0; t >>= 1) if (inside(lo - t)) lo -= t; }          // L in [p-15, p]
@@ -476,7 +472,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             } else if (m_range[k] != 0u) {           // local big node
                 const u32 rg = m_range[k];
                 const u32 L = g0 + (rg & 0xFFFFu), R = g0 + (rg >> 16);
-                const u32 q = parent_gap(L, R, ni, [&](u32 j) { return wkey((int)j); });
+                const u32 q = parent_gap(L, R, ni, [&](u32 a, u32 b) {   // both pairs lie inside the key window
+                    return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b), b, wkey((int)b + 1), b + 1u); });
                 if (q < g0 || m_range[q - g0] == M_EXT) s_task[atomicAdd(&s_npub, 1u)] = (unsigned short)(k | (q == R ? 0u : 0x8000u));
             }
         }
@@ -520,7 +517,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 
 // External nodes (ranges crossing the tiles of k_hploc_block): the sub-queues hold the nodes whose dependencies were complete
 // when the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
-__global__ __launch_bounds__(256) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+template <typename K>
+__global__ __launch_bounds__(256) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                    const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes,
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, const u32* __restrict__ q_count, u32 q_cap, u32 n) {
@@ -538,12 +536,13 @@ __global__ __launch_bounds__(256) void k_hploc_ext(const bvh_aabb* __restrict__ 
     }
 }
 
-void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, const HplocScratch& sc) {
     const u32 gaps = n - 1;
+    const dim3 g((gaps + HP_BLOCK - 1) / HP_BLOCK), b(HP_BLOCK);
     KernelScope ks(s, "k_hploc");
-    hipLaunchKernelGGL(k_hploc, dim3((gaps + HP_BLOCK - 1) / HP_BLOCK), dim3(HP_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
-                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
+    if (key_bits == 64) hipLaunchKernelGGL(k_hploc<u64>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
+    else                hipLaunchKernelGGL(k_hploc<u32>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
 }
 
 // Block-local HPLOC for large n (n > 2 tiles: the root is never local).  Tile 512 leaves / 256 threads / 7 waves per SIMD
@@ -559,29 +558,31 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, c
 #endif
 static void hpb_config(int* t, int* nt, int* occ) {
     *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
-    const char* e = getenv("BVH_HPB");                 // "T,NT,OCC" (measurements only)
+    const char* e = getenv("BVH_HPB");                 // "T,NT,OCC" (measurements only; 1024,512 is the other compiled tile)
     if (e) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { *t = a; *nt = b; *occ = c; } }
 }
 uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return (uint32_t)t; }
 // every tile may queue up to 2T nodes (its own external nodes + the parents of its maximal local ones), tiles >= 128 leaves
 size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SUB + 2) * 2 * 128 * HPQ_SUB; }
 
-void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, void* d_leaves, const HplocScratch& sc) {
     (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
     int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
     const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);
-#define HPB_LAUNCH(TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, \
+#define HPB_LAUNCH(KK, TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<KK, TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg)
     { KernelScope ks(s, "k_hploc_block");
-      if (t == 1024 && nt == 512) HPB_LAUNCH(1024, 512, 6);
-      else if (t == 256 && nt == 128) HPB_LAUNCH(256, 128, 7);
-      else HPB_LAUNCH(HPB_T, HPB_NT, HPB_OCC); }
+      if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC);
+      else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, 6);
+      else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC); }
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
-    hipLaunchKernelGGL(k_hploc_ext, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
+    if (key_bits == 64) hipLaunchKernelGGL(k_hploc_ext<u64>, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
+                       (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
+    else                hipLaunchKernelGGL(k_hploc_ext<u32>, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
                        (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
 }
 

@@ -22,8 +22,13 @@ constexpr int EM_BLOCK = 256;
 
 // ---- stage E / M (stage_em.hip)
 void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes, void* d_scene);
+void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene);
+void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene);
 void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint32_t* d_keys, uint32_t* d_vals,
                    uint32_t* d_hist /*may be null*/, int hist_bits, int passes);
+// extended Morton code with a 60-bit budget in u64 keys (total_bits = 30 reproduces launch_morton's codes: the parity pin)
+void launch_morton64(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint64_t* d_keys, int total_bits,
+                     uint32_t* d_hist /*may be null*/, int passes);
 
 // ---- stage S (sort.hip): one-sweep LSD radix sort, SORT_BITS-bit digits
 constexpr int SORT_BITS = 8;
@@ -34,10 +39,10 @@ constexpr int SORT_BLOCK = 256;
 #endif
 constexpr int SORT_IPT = BVH_SORT_IPT;                        // keys per thread
 constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup
-constexpr int SORT_MAX_PASSES = 4;
+constexpr int SORT_MAX_PASSES = 8;                          // 8 digits: 64-bit keys
 struct SortScratch {
-    uint64_t* pairs0;        // u64[n] interleaved {key,value} ping
-    uint64_t* pairs1;        // u64[n] pong
+    void*     pairs0;        // interleaved {key,value} records of the intermediate passes, ping (8 B x n for u32 keys, 16 B x n for u64)
+    void*     pairs1;        // pong
     uint32_t* hist;          // u32[SORT_MAX_PASSES * SORT_RADIX]   (zeroed by sort_prepare)
     uint32_t* status;        // u32[SORT_MAX_PASSES * tiles * SORT_RADIX] (zeroed by sort_prepare)
     uint32_t* counters;      // u32[SORT_MAX_PASSES]                 (zeroed by sort_prepare)
@@ -45,16 +50,19 @@ struct SortScratch {
 inline uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 inline int sort_passes(int start_bit, int end_bit) { return (end_bit - start_bit + SORT_BITS - 1) / SORT_BITS; }
 size_t sort_status_bytes(uint32_t n);
-// zero hist/status/counters (one memset; must precede the histogram producer)
-void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n);
+// zero hist/status/counters for `passes` digits (must precede the histogram producer)
+void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes);
 // hist_ready: sc.hist already holds the per-pass digit counts (fused into the Morton kernel); else a histogram kernel runs.
 void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
                 uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready);
+void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                  uint64_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready);
 
 // ---- stage B (lbvh.hip, hploc.hip, ploc.hip)
-void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+// key_bits: 32 = u32 sorted keys (30-bit Morton codes, the reference), 64 = u64 sorted keys (60-bit codes)
+void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root);
-void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
 // HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.
 struct HplocScratch {
@@ -68,9 +76,9 @@ struct HplocScratch {
 };
 size_t hploc_queue_capacity(uint32_t n);
 uint32_t hploc_block_tile();
-void launch_hploc(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, const HplocScratch& sc);
-void launch_hploc_block(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, void* d_leaves, const HplocScratch& sc);
 struct PlocScratch {
     void*     list0;         // 32-byte cluster entries {id, box} x n (ping)

@@ -25,7 +25,8 @@ constexpr u64 SLOT_EMPTY = ~0ull;
 // the first arriver leaves {its node index, the far end of its range} and retires; the second arriver receives it, so it
 // knows both children and the parent's full range, reads the sibling's box, and writes the parent node once (32 B).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ skeys,
+template <typename K>
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                             const u32* __restrict__ svals, bvh2_node* nodes, u64* slots,
                                                             u32* root_out, u32 n) {
     const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
         bool as_left;
         if (i == 0) as_left = true;
         else if (j == n) as_left = false;
-        else as_left = (aug_key(skeys, j - 1) ^ aug_key(skeys, j)) < (aug_key(skeys, i - 1) ^ aug_key(skeys, i));
+        else as_left = closer(skeys, j - 1, i - 1);
         const u32 p = as_left ? j - 1 : i - 1;
         const u64 mine = ((u64)cur << 32) | (as_left ? i : j);
         drain_stores();                                     // my node is in memory before anybody can learn its index
@@ -61,17 +62,18 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
 // ------------------------------------------------------------------------------------------------------------------
 // The block's key window [g0 - 256, g0 + 512] is staged in LDS: the exponential / binary searches of determineRange and
 // findSplit probe it instead of paying an L2 round trip per probe; only ranges reaching beyond the window read global memory.
-__global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ k,
+template <typename K>
+__global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restrict__ boxes, const K* __restrict__ k,
                                                        const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
                                                        u32* __restrict__ parent, u32 n) {
-    __shared__ u32 s_keys[LBVH_BLOCK * 3 + 1];
+    __shared__ K s_keys[LBVH_BLOCK * 3 + 1];
     const int g0 = (int)(blockIdx.x * LBVH_BLOCK), w0 = g0 - LBVH_BLOCK;
-    for (int t = threadIdx.x; t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : 0u; }
+    for (int t = threadIdx.x; t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : (K)0; }
     __syncthreads();
-    auto key_at = [&](u32 j) -> u32 { return ((u32)((int)j - w0) <= (u32)(LBVH_BLOCK * 3)) ? s_keys[(int)j - w0] : k[j]; };
-    auto delta2p = [&](u32 i, u32 j) -> int {                  // countCommonPrefixBits as used at :52-54
-        const u32 a = key_at(i), b = key_at(j);
-        return (a == b) ? (32 + __clz((int)(i ^ j))) : __clz((int)(a ^ b));
+    auto key_at = [&](u32 j) -> K { return ((u32)((int)j - w0) <= (u32)(LBVH_BLOCK * 3)) ? s_keys[(int)j - w0] : k[j]; };
+    auto delta2p = [&](u32 i, u32 j) -> int {                  // countCommonPrefixBits as used at :52-54 (u32: 32 + clz(i^j) / clz(a^b))
+        const K a = key_at(i), b = key_at(j);
+        return (a == b) ? ((int)sizeof(K) * 8 + clz_u32(i ^ j)) : (sizeof(K) == 4 ? clz_u32((u32)(a ^ b)) : clz_u64((u64)(a ^ b)));
     };
     const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
     if (g >= n) return;
@@ -132,19 +134,23 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-void launch_lbvh_single(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+// key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes)
+void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots, uint32_t* d_root) {
-    hipMemsetAsync(d_slots, 0xFF, (size_t)n * sizeof(u64), s);
+    (void)hipMemsetAsync(d_slots, 0xFF, (size_t)n * sizeof(u64), s);
     const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    { KernelScope ks(s, "k_lbvh_single"); hipLaunchKernelGGL(k_lbvh_single, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals,
-                       (bvh2_node*)d_nodes, d_slots, d_root, n); }
+    KernelScope ks(s, "k_lbvh_single");
+    if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_single<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
+    else                hipLaunchKernelGGL(k_lbvh_single<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
 }
 
-void launch_lbvh_two(hipStream_t s, const void* d_boxes, const uint32_t* d_skeys, const uint32_t* d_svals, uint32_t n,
+void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent, uint32_t* d_flags) {
-    hipMemsetAsync(d_flags, 0xFF, (size_t)n * sizeof(u32), s);
+    (void)hipMemsetAsync(d_flags, 0xFF, (size_t)n * sizeof(u32), s);
     const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    { KernelScope ks(s, "k_karras"); hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n); }
+    { KernelScope ks(s, "k_karras");
+      if (key_bits == 64) hipLaunchKernelGGL(k_karras<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n);
+      else                hipLaunchKernelGGL(k_karras<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n); }
     { KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n); }
 }
 

@@ -1,4 +1,5 @@
-// sort.hip — stage S: one-sweep LSD radix sort of (u32 key, u32 value) pairs for gfx950.
+// sort.hip — stage S: one-sweep LSD radix sort of (key, u32 value) pairs for gfx950; keys are u32 (the reference's 30-bit
+// Morton codes) or u64 (60-bit codes).
 //
 // Replaces Oro::RadixSort::sort(KeyValueSoA src, KeyValueSoA dst, n, startBit, endBit, stream) — the reference's only
 // use of the (un-vendored) Orochi library on this path; call sites src/TwoPassLbvh.cpp:71-89, src/SinglePassLbvh.cpp:72-90,
@@ -23,19 +24,35 @@ namespace bvh {
 static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit");
 constexpr u32 ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 
+// interleaved {key, value} records of the intermediate passes: 8 bytes for u32 keys, 16 bytes {key, value, pad} for u64 keys
+template <typename K> struct PairRec;
+template <> struct PairRec<u32> {
+    using type = u64;
+    static __device__ __forceinline__ type pack(u32 k, u32 v) { return (u64)k | ((u64)v << 32); }
+    static __device__ __forceinline__ u32 key(type r) { return (u32)r; }
+    static __device__ __forceinline__ u32 val(type r) { return (u32)(r >> 32); }
+};
+template <> struct PairRec<u64> {
+    using type = uint4;
+    static __device__ __forceinline__ type pack(u64 k, u32 v) { return make_uint4((u32)k, (u32)(k >> 32), v, 0u); }
+    static __device__ __forceinline__ u64 key(type r) { return (u64)r.x | ((u64)r.y << 32); }
+    static __device__ __forceinline__ u32 val(type r) { return r.z; }
+};
+
 // stand-alone histogram (all passes in one read of the keys)
-__global__ __launch_bounds__(SORT_BLOCK) void k_hist(const u32* __restrict__ keys, u32 n, int start_bit, int end_bit, int passes,
+template <typename K>
+__global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys, u32 n, int start_bit, int end_bit, int passes,
                                                      u32* __restrict__ hist) {
     __shared__ u32 s_hist[SORT_MAX_PASSES * SORT_RADIX];
     for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) s_hist[i] = 0;
     __syncthreads();
     const u32 stride = gridDim.x * SORT_BLOCK;
     for (u32 i = blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += stride) {
-        const u32 k = keys[i];
+        const K k = keys[i];
         for (int p = 0; p < passes; ++p) {
             const int sh = start_bit + p * SORT_BITS;
             const int w = min(SORT_BITS, end_bit - sh);
-            atomicAdd(&s_hist[p * SORT_RADIX + ((k >> sh) & ((1u << w) - 1u))], 1u);
+            atomicAdd(&s_hist[p * SORT_RADIX + ((u32)(k >> sh) & ((1u << w) - 1u))], 1u);
         }
     }
     __syncthreads();
@@ -61,16 +78,17 @@ __global__ __launch_bounds__(SORT_RADIX) void k_scan_hist(u32* __restrict__ hist
 // IN_AOS / OUT_AOS: the pair arrays of the intermediate passes are interleaved {key, value} u64 words — a tile's run for one
 // digit is then 16 x 8 B = a full 128-byte line instead of two 64-byte half lines (measured: scattered SoA writes cost 36 % of a
 // pass).  The caller-facing arrays of the first and last pass stay SoA (KeyValueSoA of Oro::RadixSort::sort).
-template <bool IOTA, bool IN_AOS, bool OUT_AOS>
-__global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
-                                                         u32* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS>
+__global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                         K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
                                                          int shift, u32 digit_mask, const u32* __restrict__ ghist,
                                                          u32* status, u32* tile_counter, int dbg) {
     constexpr int NW = SORT_BLOCK / WAVE;
     __shared__ u32 s_whist[NW][SORT_RADIX];
     __shared__ u32 s_binoff[SORT_RADIX];
     __shared__ u32 s_gbase[SORT_RADIX];
-    __shared__ u32 s_keys[SORT_TILE];
+    using Rec = PairRec<K>;
+    __shared__ K s_keys[SORT_TILE];
     __shared__ u32 s_vals[SORT_TILE];
     __shared__ u32 s_wsum[NW];
     __shared__ u32 s_tile;
@@ -85,16 +103,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
     const u32 valid = min((u32)SORT_TILE, n - base);
 
     // ---- load (wave-striped: wave w owns a contiguous 64*IPT span, item i is a coalesced 256-B row of it)
-    u32 key[SORT_IPT], val[SORT_IPT], pos[SORT_IPT];
+    K key[SORT_IPT]; u32 val[SORT_IPT], pos[SORT_IPT];
 #pragma unroll
     for (int i = 0; i < SORT_IPT; ++i) {
         const u32 local = (u32)(wave * WAVE * SORT_IPT + i * WAVE + lane);
         const bool ok = local < valid;
         if (IN_AOS) {
-            const u64 kv = ok ? reinterpret_cast<const u64*>(keys_in)[base + local] : 0xFFFFFFFFull;
-            key[i] = (u32)kv; val[i] = (u32)(kv >> 32);
+            if (ok) { const typename Rec::type kv = reinterpret_cast<const typename Rec::type*>(keys_in)[base + local]; key[i] = Rec::key(kv); val[i] = Rec::val(kv); }
+            else { key[i] = ~(K)0; val[i] = 0u; }
         } else {
-            key[i] = ok ? keys_in[base + local] : 0xFFFFFFFFu;
+            key[i] = ok ? keys_in[base + local] : ~(K)0;
             val[i] = IOTA ? (base + local) : (ok ? vals_in[base + local] : 0u);
         }
     }
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
     const u64 lt = lanemask_lt();
 #pragma unroll
     for (int i = 0; i < SORT_IPT; ++i) {
-        const u32 d = (key[i] >> shift) & digit_mask;
+        const u32 d = (u32)(key[i] >> shift) & digit_mask;
         u64 grp = ~0ull;
 #pragma unroll
         for (int b = 0; b < SORT_BITS; ++b) {
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
     // ---- tile-local sort through LDS
 #pragma unroll
     for (int i = 0; i < SORT_IPT; ++i) {
-        const u32 d = (key[i] >> shift) & digit_mask;
+        const u32 d = (u32)(key[i] >> shift) & digit_mask;
         const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
         s_keys[p] = key[i]; s_vals[p] = val[i];
     }
@@ -186,9 +204,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const u32* __restrict__
     for (int k = 0; k < SORT_IPT; ++k) {
         const u32 p = (u32)(k * SORT_BLOCK + tid);
         if (p < valid) {
-            const u32 kk = s_keys[p];
-            const u32 dst = (dbg & 2) ? base + p : s_gbase[(kk >> shift) & digit_mask] + p;
-            if (OUT_AOS) reinterpret_cast<u64*>(keys_out)[dst] = (u64)kk | ((u64)s_vals[p] << 32);
+            const K kk = s_keys[p];
+            const u32 dst = (dbg & 2) ? base + p : s_gbase[(u32)(kk >> shift) & digit_mask] + p;
+            if (OUT_AOS) reinterpret_cast<typename Rec::type*>(keys_out)[dst] = Rec::pack(kk, s_vals[p]);
             else { keys_out[dst] = kk; vals_out[dst] = s_vals[p]; }
         }
     }
@@ -201,18 +219,19 @@ __global__ void k_iota(u32* __restrict__ out, u32 n) {
 
 size_t sort_status_bytes(uint32_t n) { return (size_t)SORT_MAX_PASSES * sort_tiles(n) * SORT_RADIX * sizeof(u32); }
 
-void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n) {
-    hipMemsetAsync(sc.hist, 0, SORT_MAX_PASSES * SORT_RADIX * sizeof(u32), s);
-    hipMemsetAsync(sc.status, 0, sort_status_bytes(n), s);
-    hipMemsetAsync(sc.counters, 0, SORT_MAX_PASSES * sizeof(u32), s);
+void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes) {
+    (void)hipMemsetAsync(sc.hist, 0, (size_t)passes * SORT_RADIX * sizeof(u32), s);
+    (void)hipMemsetAsync(sc.status, 0, (size_t)passes * sort_tiles(n) * SORT_RADIX * sizeof(u32), s);
+    (void)hipMemsetAsync(sc.counters, 0, SORT_MAX_PASSES * sizeof(u32), s);
 }
 
-void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
-                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
+template <typename K>
+static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in, const uint32_t* vals_in, uint32_t n,
+                         K* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
     const int passes = sort_passes(start_bit, end_bit);
     if (passes <= 0) {   // nothing to sort on: identity permutation
-        hipMemcpyAsync(keys_out, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
-        if (vals_in) hipMemcpyAsync(vals_out, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, s);
+        if (vals_in) (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
         else hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, vals_out, n);
         return;
     }
@@ -220,19 +239,19 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
     if (!hist_ready) {
         const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
         KernelScope ks(s, "k_hist");
-        hipLaunchKernelGGL(k_hist, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
+        hipLaunchKernelGGL(k_hist<K>, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
     { KernelScope ks(s, "k_scan_hist"); hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist); }
-    #ifdef BVH_ABLATION
+#ifdef BVH_ABLATION
     const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // measurements only: results are wrong when set
 #else
     const int dbg = 0;
 #endif
-    const u32* kin = keys_in; const u32* vin = vals_in;
+    const K* kin = keys_in; const u32* vin = vals_in;
     for (int p = 0; p < passes; ++p) {
         const bool first = p == 0, last = p == passes - 1;
-        // intermediate pair arrays: interleaved u64 ping-pong buffers pairs0 / pairs1
-        u32* kout = last ? keys_out : reinterpret_cast<u32*>((p & 1) ? sc.pairs1 : sc.pairs0);
+        // intermediate pair arrays: interleaved ping-pong buffers pairs0 / pairs1
+        K* kout = last ? keys_out : reinterpret_cast<K*>((p & 1) ? sc.pairs1 : sc.pairs0);
         u32* vout = last ? vals_out : nullptr;
         const int sh = start_bit + p * SORT_BITS;
         const int w = (end_bit - sh) < SORT_BITS ? (end_bit - sh) : SORT_BITS;
@@ -242,7 +261,7 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
         u32* tc = sc.counters + p;
         KernelScope ks(s, "k_onesweep");
         const dim3 g(tiles), b(SORT_BLOCK);
-#define SWEEP(IOTA, INA, OUTA) hipLaunchKernelGGL((k_onesweep<IOTA, INA, OUTA>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg)
+#define SWEEP(IOTA, INA, OUTA) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg)
         if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }
         else if (last)          SWEEP(false, true, false);
@@ -250,6 +269,15 @@ void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, c
 #undef SWEEP
         kin = kout; vin = vout;
     }
+}
+
+void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
+    sort_pairs_t<u32>(s, sc, keys_in, vals_in, n, keys_out, vals_out, start_bit, end_bit, hist_ready);
+}
+void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                  uint64_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
+    sort_pairs_t<u64>(s, sc, keys_in, vals_in, n, keys_out, vals_out, start_bit, end_bit, hist_ready);
 }
 
 } // namespace bvh

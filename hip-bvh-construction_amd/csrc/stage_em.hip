@@ -32,6 +32,21 @@ __device__ __forceinline__ Box wave_reduce_box(Box b) {
     return b;
 }
 
+// block AABB -> scene extent: wave64 shuffles + one LDS hop + 6 integer-punned float atomics per block
+__device__ __forceinline__ void block_reduce_scene(Box acc, float* __restrict__ scene) {
+    acc = wave_reduce_box(acc);
+    __shared__ float red[EM_BLOCK / WAVE][6];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (lane == 0) { red[wave][0] = acc.lx; red[wave][1] = acc.ly; red[wave][2] = acc.lz; red[wave][3] = acc.hx; red[wave][4] = acc.hy; red[wave][5] = acc.hz; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < EM_BLOCK / WAVE; ++w) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomic_min_f32(scene + threadIdx.x, v); else atomic_max_f32(scene + threadIdx.x, v);
+    }
+}
+
 __global__ __launch_bounds__(EM_BLOCK) void k_extents(const float4* __restrict__ tris, bvh_aabb* __restrict__ boxes,
                                                       float* __restrict__ scene, u32 n) {
     Box acc = box_empty();
@@ -47,17 +62,54 @@ __global__ __launch_bounds__(EM_BLOCK) void k_extents(const float4* __restrict__
         box_store(boxes + i, bx);
         acc = box_union(acc, bx);
     }
-    acc = wave_reduce_box(acc);
-    __shared__ float red[EM_BLOCK / WAVE][6];
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    if (lane == 0) { red[wave][0] = acc.lx; red[wave][1] = acc.ly; red[wave][2] = acc.lz; red[wave][3] = acc.hx; red[wave][4] = acc.hy; red[wave][5] = acc.hz; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < EM_BLOCK / WAVE; ++w) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
-        if (threadIdx.x < 3) atomic_min_f32(scene + threadIdx.x, v); else atomic_max_f32(scene + threadIdx.x, v);
+    block_reduce_scene(acc, scene);
+}
+
+// SURVEY.md §8(f) row 4 — device-side ingestion formats that do not pay for the reference's 64-byte padding.
+// Packed: 9 floats per triangle (36-byte stride).  A block stages 256 triangles (9216 contiguous bytes) through LDS with
+// 16-byte loads; each thread then reads its 9 floats at a stride of 9 words (odd: conflict-free).  R 36 + W 24 B / prim.
+__global__ __launch_bounds__(EM_BLOCK) void k_extents_packed(const float* __restrict__ tris, bvh_aabb* __restrict__ boxes,
+                                                             float* __restrict__ scene, u32 n) {
+    __shared__ float s_t[EM_BLOCK * 9];
+    Box acc = box_empty();
+    const u32 tiles = (n + EM_BLOCK - 1) / EM_BLOCK;
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const u32 base = tile * EM_BLOCK;
+        const u32 cnt = (n - base) < (u32)EM_BLOCK ? (n - base) : (u32)EM_BLOCK;
+        const float* src = tris + (size_t)base * 9;                      // 16-byte aligned: EM_BLOCK * 36 is a multiple of 16
+        const u32 words = cnt * 9u, vecs = words / 4u;
+        for (u32 v = threadIdx.x; v < vecs; v += EM_BLOCK) reinterpret_cast<float4*>(s_t)[v] = reinterpret_cast<const float4*>(src)[v];
+        for (u32 k = vecs * 4u + threadIdx.x; k < words; k += EM_BLOCK) s_t[k] = src[k];
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const float* t = s_t + threadIdx.x * 9;
+            Box bx;
+            bx.lx = fminf(fminf(t[0], t[3]), t[6]); bx.ly = fminf(fminf(t[1], t[4]), t[7]); bx.lz = fminf(fminf(t[2], t[5]), t[8]);
+            bx.hx = fmaxf(fmaxf(t[0], t[3]), t[6]); bx.hy = fmaxf(fmaxf(t[1], t[4]), t[7]); bx.hz = fmaxf(fmaxf(t[2], t[5]), t[8]);
+            box_store(boxes + base + threadIdx.x, bx);
+            acc = box_union(acc, bx);
+        }
+        __syncthreads();
     }
+    block_reduce_scene(acc, scene);
+}
+
+// Indexed: float3 vertices + uint3 indices.  R 12 (indices) + 3 vertex gathers (12 B each, shared vertices hit in L2) + W 24 B / prim.
+__global__ __launch_bounds__(EM_BLOCK) void k_extents_indexed(const float* __restrict__ verts, const u32* __restrict__ idx, u32 n_verts,
+                                                              bvh_aabb* __restrict__ boxes, float* __restrict__ scene, u32 n) {
+    Box acc = box_empty();
+    const u32 stride = gridDim.x * EM_BLOCK;
+    for (u32 i = blockIdx.x * EM_BLOCK + threadIdx.x; i < n; i += stride) {
+        u32 i0 = idx[(size_t)i * 3 + 0], i1 = idx[(size_t)i * 3 + 1], i2 = idx[(size_t)i * 3 + 2];
+        if (i0 >= n_verts) i0 = 0; if (i1 >= n_verts) i1 = 0; if (i2 >= n_verts) i2 = 0;   // never read out of bounds
+        const float* a = verts + (size_t)i0 * 3; const float* b = verts + (size_t)i1 * 3; const float* c = verts + (size_t)i2 * 3;
+        Box bx;
+        bx.lx = fminf(fminf(a[0], b[0]), c[0]); bx.ly = fminf(fminf(a[1], b[1]), c[1]); bx.lz = fminf(fminf(a[2], b[2]), c[2]);
+        bx.hx = fmaxf(fmaxf(a[0], b[0]), c[0]); bx.hy = fmaxf(fmaxf(a[1], b[1]), c[1]); bx.hz = fmaxf(fmaxf(a[2], b[2]), c[2]);
+        box_store(boxes + i, bx);
+        acc = box_union(acc, bx);
+    }
+    block_reduce_scene(acc, scene);
 }
 
 __global__ void k_reset_scene(float* scene) {   // Aabb::reset on d_sceneExtents (src/PLOC++Bvh.cpp:23-25)
@@ -86,7 +138,8 @@ __device__ __forceinline__ u32 sat_f2u(float f) {
 }
 __device__ __forceinline__ int lg_ratio(float num, float den) { return sat_f2i(log2f(num / den)); }
 
-__device__ void make_plan(const float* __restrict__ scene, MortonPlan& m, float* lo, float* ext) {
+// NB: total bit budget of the code — 30 in the reference (:161); 60 for the u64 keys of SURVEY.md §8(f) row 3 (same arithmetic)
+__device__ void make_plan(const float* __restrict__ scene, MortonPlan& m, float* lo, float* ext, const u32 NB = 30u) {
     lo[0] = scene[0]; lo[1] = scene[1]; lo[2] = scene[2];
     const float ex = scene[3] - scene[0], ey = scene[4] - scene[1], ez = scene[5] - scene[2];
     ext[0] = ex; ext[1] = ey; ext[2] = ez;
@@ -103,7 +156,6 @@ __device__ void make_plan(const float* __restrict__ scene, MortonPlan& m, float*
             else         { m.axis[0] = 0; m.axis[1] = 2; m.axis[2] = 1; px = lg_ratio(ex, ez); py = lg_ratio(ez, ey); pz = lg_ratio(ex, ey); }
         } else           { m.axis[0] = 0; m.axis[1] = 1; m.axis[2] = 2; px = lg_ratio(ex, ey); py = lg_ratio(ey, ez); pz = lg_ratio(ex, ez); }
     }
-    const u32 NB = 30u;
     int swap = (int)((u32)pz - ((u32)px + (u32)py));                                   // :252
     px = (int)fmin((double)px, (double)NB);                                            // :254
     py = (int)(fmin((double)(int)((u32)py * 2u), (double)(NB - (u32)px)) / 2.0);       // :255
@@ -157,6 +209,79 @@ __device__ __forceinline__ u32 encode(const MortonPlan& m, float p0, float p1, f
     return code;
 }
 
+// ---- 64-bit flavour of encode(): the same steps with every intermediate 64 bits wide, for bit budgets up to 60 (<= 20 bits per
+// axis in the 3-D part, <= 30 in the 2-D parts).  With a 30-bit budget it reproduces encode() bit for bit (tests pin that).
+__device__ __forceinline__ u64 shl64(u64 v, u32 s) { return s >= 64u ? 0ull : v << s; }
+__device__ __forceinline__ u64 shr64(u64 v, u32 s) { return s >= 64u ? 0ull : v >> s; }
+__device__ __forceinline__ u64 spread2_64(u64 v) {   // bit i -> bit 2i, 32-bit input
+    v &= 0x00000000ffffffffull; v = (v ^ (v << 16)) & 0x0000ffff0000ffffull; v = (v ^ (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v ^ (v << 4)) & 0x0f0f0f0f0f0f0f0full; v = (v ^ (v << 2)) & 0x3333333333333333ull; v = (v ^ (v << 1)) & 0x5555555555555555ull; return v;
+}
+__device__ __forceinline__ u64 spread3_64(u64 x) {   // bit i -> bit 3i, 21-bit input
+    x &= 0x1fffffull; x = (x | (x << 32)) & 0x1f00000000ffffull; x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full; x = (x | (x << 4)) & 0x10c30c30c30c30c3ull; x = (x | (x << 2)) & 0x1249249249249249ull; return x;
+}
+__device__ __forceinline__ u64 sat_f2u64(float f) {
+    if (f != f) return 0ull;
+    if (f <= 0.0f) return 0ull;
+    if (f >= 18446744073709551616.0f) return ~0ull;
+    return (u64)f;
+}
+__device__ __forceinline__ u64 quantise64(float p, int bits) {
+    const u64 top = shl64(1ull, (u32)bits);
+    const u64 q = sat_f2u64(fmaxf(p * (float)top, 0.0f));
+    return q < top - 1ull ? q : top - 1ull;
+}
+__device__ __forceinline__ u64 encode64(const MortonPlan& m, float p0, float p1, float p2) {
+    int bx = m.bits[0], by = m.bits[1];
+    const int bz = m.bits[2], px = m.pre[0], py = m.pre[1];
+    u64 q0 = quantise64(p0, bx), q1 = quantise64(p1, by), q2 = quantise64(p2, bz);
+    u64 code = 0; u32 d0 = 0, d1 = 0;
+    if (m.pre_sum > 0) {
+        bx -= px;
+        code = shr64(q0 & shl64(shl64(1ull, (u32)px) - 1ull, (u32)bx), (u32)bx);
+        code = shl64(code, (u32)(py * 2));
+        bx -= py; by -= py;
+        const u64 t0 = spread2_64(shr64(q0 & shl64(shl64(1ull, (u32)py) - 1ull, (u32)bx), (u32)bx));
+        const u64 t1 = spread2_64(shr64(q1 & shl64(shl64(1ull, (u32)py) - 1ull, (u32)by), (u32)by));
+        code |= t0 * 2 + t1;
+        if (m.swap > 0) { code <<= 1; bx -= 1; code |= shr64(q0 & shl64(1ull, (u32)bx), (u32)bx); }
+        code = shl64(code, (u32)(bx + by + bz));
+        q0 &= shl64(1ull, (u32)bx) - 1ull;
+        q1 &= shl64(1ull, (u32)by) - 1ull;
+        if (m.swap > 0) { d0 = (u32)(by - bx); q0 = shl64(q0, d0); d1 = (u32)(by - bz); q2 = shl64(q2, d1); }
+        else            { d0 = (u32)(bx - by); q1 = shl64(q1, d0); d1 = (u32)(bx - bz); q2 = shl64(q2, d1); }
+    }
+    if (bz == 0) code |= spread2_64(q0) * 2 + spread2_64(q1);
+    else {
+        const u64 X = spread3_64(q0), Y = spread3_64(q1), Z = spread3_64(q2);
+        code |= shr64((m.swap > 0) ? (Y * 4 + X * 2 + Z) : (X * 4 + Y * 2 + Z), d0 + d1);
+    }
+    return code;
+}
+
+// u64 keys with a `total_bits` budget; the 8-bit digit histograms of the `passes` sort passes that follow are fused in as in k_morton
+__global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
+                                                       u64* __restrict__ keys, u32 n, u32 total_bits, u32* __restrict__ hist, int passes) {
+    __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
+    __shared__ u32 s_hist[8 * 256];
+    if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext, total_bits);
+    for (int i = threadIdx.x; i < passes * 256; i += EM_BLOCK) s_hist[i] = 0;
+    __syncthreads();
+    const MortonPlan m = s_plan;
+    const float lo[3] = { s_lo[0], s_lo[1], s_lo[2] }, ext[3] = { s_ext[0], s_ext[1], s_ext[2] };
+    const u32 stride = gridDim.x * EM_BLOCK;
+    for (u32 i = blockIdx.x * EM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const Box b = box_load(boxes + i);
+        const float p[3] = { ((b.hx + b.lx) * 0.5f - lo[0]) / ext[0], ((b.hy + b.ly) * 0.5f - lo[1]) / ext[1], ((b.hz + b.lz) * 0.5f - lo[2]) / ext[2] };
+        const u64 code = encode64(m, p[m.axis[0]], p[m.axis[1]], p[m.axis[2]]);
+        keys[i] = code;
+        for (int ps = 0; ps < passes; ++ps) atomicAdd(&s_hist[ps * 256 + ((u32)(code >> (ps * 8)) & 255u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * 256; i += EM_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&hist[i], c); }
+}
+
 // HIST_BITS > 0: also accumulate the per-pass digit histograms of the LSD radix sort that follows (digits of HIST_BITS
 // bits starting at bit 0, `passes` of them) — LDS histogram per block, flushed with one global atomic per non-empty bin.
 template <int HIST_BITS>
@@ -200,6 +325,17 @@ void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, voi
     { KernelScope ks(s, "k_extents"); hipLaunchKernelGGL(k_extents, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n); }
 }
 
+void launch_extents_packed(hipStream_t s, const void* d_tris36, u32 n, void* d_boxes, void* d_scene) {
+    hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
+    KernelScope ks(s, "k_extents_packed");
+    hipLaunchKernelGGL(k_extents_packed, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float*)d_tris36, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+}
+void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, u32 n_vertices, u32 n, void* d_boxes, void* d_scene) {
+    hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
+    KernelScope ks(s, "k_extents_indexed");
+    hipLaunchKernelGGL(k_extents_indexed, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float*)d_vertices, (const u32*)d_indices, n_vertices, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+}
+
 void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
                    u32* d_hist, int hist_bits, int passes) {
     const dim3 g(em_grid(n)), b(EM_BLOCK);
@@ -207,6 +343,12 @@ void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scen
     if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
     else if (d_hist && hist_bits == 10) hipLaunchKernelGGL(k_morton<10>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
     else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0);
+}
+
+void launch_morton64(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, uint64_t* d_keys, int total_bits, u32* d_hist, int passes) {
+    KernelScope ks(s, "k_morton64");
+    hipLaunchKernelGGL(k_morton64, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, n, (u32)total_bits,
+                       d_hist, d_hist ? passes : 0);
 }
 
 } // namespace bvh

@@ -80,12 +80,42 @@ typedef struct {
     uint32_t n_internal;          /* n - 1 (m_nInternalNodes) */
     uint32_t n_leaves;            /* n */
     uint32_t layout;              /* 0 = LBVH layout, 1 = PLOC layout */
+    uint32_t key_bits;            /* 32: d_sorted_keys is u32[n] (30-bit codes, the reference); 64: u64[n] (60-bit codes, bvh_build_ex) */
+    uint32_t reserved;
 } bvh_result;
 
 /* X::build(Context&, std::vector<Triangle>&).  tris: Triangle[n], 64-byte stride, host (tris_on_device = 0: copied H2D
  * into the ctx arena, untimed, as src/TwoPassLbvh.cpp:19-20 does) or device (tris_on_device = 1: used in place). n >= 2. */
 int  bvh_build(bvh_ctx* ctx, bvh_algo algo, const void* tris, uint32_t n, int tris_on_device,
                bvh_result* out, bvh_timings* timings /* may be NULL */);
+
+/* ---- extended build (no counterpart in the reference) -----------------------------------
+ * Input formats that do not pay for the reference's 64-byte padded Triangle records (stage E reads 36 or ~18 bytes per
+ * triangle instead of 64), and 60-bit Morton codes in u64 keys (the same extended-code arithmetic as
+ * computeExtendedMortonCode with a 60-bit budget; 8 one-sweep passes; the emitters compare 96-bit {key, position} words).
+ * All pointers are DEVICE pointers.  Trees built from the same triangles are identical across input formats. */
+typedef enum {
+    BVH_TRI_PADDED64 = 0,   /* Triangle[n], 64-byte stride (src/Common.h:429-434) — the reference layout */
+    BVH_TRI_PACKED36 = 1,   /* float[9n]: v1 v2 v3 per triangle, 36-byte stride; d_tris 16-byte aligned */
+    BVH_TRI_INDEXED  = 2    /* float[3*n_vertices] + uint32[3n] */
+} bvh_tri_format;
+typedef struct {
+    uint32_t    tri_format;      /* bvh_tri_format */
+    uint32_t    morton_bits;     /* 30 (reference) or 60 */
+    const void* d_tris;          /* PADDED64 / PACKED36 */
+    const void* d_vertices;      /* INDEXED */
+    const void* d_indices;       /* INDEXED */
+    uint32_t    n_vertices;      /* INDEXED (indices >= n_vertices are read as vertex 0, never out of bounds) */
+    uint32_t    reserved;
+} bvh_build_input;
+int  bvh_build_ex(bvh_ctx* ctx, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* timings /* may be NULL */);
+/* stage E on any input format */
+int  bvh_stage_extents_ex(bvh_ctx* ctx, const bvh_build_input* in, uint32_t n, void* d_prim_aabbs, void* d_scene_extent);
+/* stage M with a total_bits budget (<= 60) into u64 keys; total_bits = 30 reproduces bvh_stage_morton's codes */
+int  bvh_stage_morton64(bvh_ctx* ctx, const void* d_prim_aabbs, uint32_t n, const void* d_scene_extent, uint64_t* d_keys, int total_bits);
+/* stage S on u64 keys, key bits [start_bit, end_bit) with end_bit <= 64 */
+int  bvh_sort_pairs64(bvh_ctx* ctx, const uint64_t* d_keys_in, const uint32_t* d_vals_in, uint32_t n,
+                      uint64_t* d_keys_out, uint32_t* d_vals_out, int start_bit, int end_bit);
 
 /* ---- stage-level entry points (one per reference kernel / library call on the path) -------------------------- */
 
@@ -133,8 +163,9 @@ int  bvh_trace_while(bvh_ctx* ctx, const void* d_rays, const void* d_tris, const
                      const void* h_transform, void* d_rgba, uint32_t width, uint32_t height);
 /* BVH2 SAH cost with the formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349), device reduction, f64. */
 int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
-/* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL */
-int  bvh_download(bvh_ctx* ctx, const bvh_result* in, void* h_nodes, void* h_leaves, uint32_t* h_sorted_keys,
+/* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL.  h_sorted_keys: u32[n] or, for
+ * key_bits == 64 results, u64[n] */
+int  bvh_download(bvh_ctx* ctx, const bvh_result* in, void* h_nodes, void* h_leaves, void* h_sorted_keys,
                   uint32_t* h_sorted_vals, void* h_scene_extent);
 
 /* BatchedBvhBuilder::build (src/BatchedBuilder.h:12-31) re-purposed as the multi-GPU scene shard (BASELINE.json config 5), one

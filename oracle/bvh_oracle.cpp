@@ -94,7 +94,7 @@ struct MortonPlan {
 inline double dmin(double a, double b) { return a < b ? a : b; }
 inline double dmax(double a, double b) { return a > b ? a : b; }
 
-MortonPlan morton_plan(const F3& e) {
+MortonPlan morton_plan(const F3& e, const u32 NB = 30) {   // NB: bit budget — 30 in the reference (:161); 60 = the u64 extension
     MortonPlan m;
     const float ext[3] = { e.x, e.y, e.z };
     int px, py, pz;
@@ -111,7 +111,6 @@ MortonPlan morton_plan(const F3& e) {
             else           { m.axis[0] = 0; m.axis[1] = 2; m.axis[2] = 1; px = lg(e.x, e.z); py = lg(e.z, e.y); pz = lg(e.x, e.y); }
         } else             { m.axis[0] = 0; m.axis[1] = 1; m.axis[2] = 2; px = lg(e.x, e.y); py = lg(e.y, e.z); pz = lg(e.x, e.z); }
     }
-    const u32 NB = 30;                                              // :161
     int swap = wrap_sub(pz, wrap_add(px, py));                      // :252
     px = (int)dmin((double)px, (double)NB);                         // :254
     py = (int)(dmin((double)wrap_mul2(py), (double)(u32)(NB - (u32)px)) / 2);   // :255 (double divide, then trunc)
@@ -184,6 +183,57 @@ u32 morton_encode(const MortonPlan& m, const float pos[3]) {        // :277-358
     return code;
 }
 
+// 64-bit flavour of morton_encode for bit budgets up to 60 (no reference counterpart; the same steps
+// with 64-bit intermediates — with NB = 30 it must reproduce morton_encode bit for bit, which tests pin).
+inline u64 shl64(u64 v, u32 s) { return s >= 64 ? 0ull : v << s; }
+inline u64 shr64(u64 v, u32 s) { return s >= 64 ? 0ull : v >> s; }
+inline u64 spread2_64(u64 v) {
+    v &= 0x00000000ffffffffull; v = (v ^ (v << 16)) & 0x0000ffff0000ffffull; v = (v ^ (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v ^ (v << 4)) & 0x0f0f0f0f0f0f0f0full; v = (v ^ (v << 2)) & 0x3333333333333333ull; v = (v ^ (v << 1)) & 0x5555555555555555ull; return v;
+}
+inline u64 spread3_64(u64 x) {
+    x &= 0x1fffffull; x = (x | (x << 32)) & 0x1f00000000ffffull; x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full; x = (x | (x << 4)) & 0x10c30c30c30c30c3ull; x = (x | (x << 2)) & 0x1249249249249249ull; return x;
+}
+inline u64 sat_f2u64(float f) {
+    if (f != f) return 0ull;
+    if (f <= 0.0f) return 0ull;
+    if (f >= 18446744073709551616.0f) return ~0ull;
+    return (u64)f;
+}
+inline u64 quantise64(float p, int bits) {
+    const u64 top = shl64(1ull, (u32)bits);
+    const u64 q = sat_f2u64(fmaxf(p * (float)top, 0.0f));
+    return std::min<u64>(q, top - 1ull);
+}
+u64 morton_encode64(const MortonPlan& m, const float pos[3]) {
+    int bx = m.bits[0], by = m.bits[1], bz = m.bits[2];
+    const int px = m.pre[0], py = m.pre[1];
+    u64 q0 = quantise64(pos[m.axis[0]], bx), q1 = quantise64(pos[m.axis[1]], by), q2 = quantise64(pos[m.axis[2]], bz);
+    u64 code = 0; u32 d0 = 0, d1 = 0;
+    if (m.pre_sum > 0) {
+        bx -= px;
+        code = shr64(q0 & shl64(shl64(1ull, (u32)px) - 1ull, (u32)bx), (u32)bx);
+        code = shl64(code, (u32)(py * 2));
+        bx -= py; by -= py;
+        const u64 t0 = spread2_64(shr64(q0 & shl64(shl64(1ull, (u32)py) - 1ull, (u32)bx), (u32)bx));
+        const u64 t1 = spread2_64(shr64(q1 & shl64(shl64(1ull, (u32)py) - 1ull, (u32)by), (u32)by));
+        code |= t0 * 2 + t1;
+        if (m.swap > 0) { code <<= 1; bx -= 1; code |= shr64(q0 & shl64(1ull, (u32)bx), (u32)bx); }
+        code = shl64(code, (u32)(bx + by + bz));
+        q0 &= shl64(1ull, (u32)bx) - 1ull;
+        q1 &= shl64(1ull, (u32)by) - 1ull;
+        if (m.swap > 0) { d0 = (u32)(by - bx); q0 = shl64(q0, d0); d1 = (u32)(by - bz); q2 = shl64(q2, d1); }
+        else            { d0 = (u32)(bx - by); q1 = shl64(q1, d0); d1 = (u32)(bx - bz); q2 = shl64(q2, d1); }
+    }
+    if (bz == 0) code |= spread2_64(q0) * 2 + spread2_64(q1);
+    else {
+        const u64 X = spread3_64(q0), Y = spread3_64(q1), Z = spread3_64(q2);
+        code |= shr64((m.swap > 0) ? (Y * 4 + X * 2 + Z) : (X * 4 + Y * 2 + Z), d0 + d1);
+    }
+    return code;
+}
+
 // ------------------------------------------------------------------------------------------------
 // delta functions used by the hierarchy emitters
 // ------------------------------------------------------------------------------------------------
@@ -195,6 +245,15 @@ inline int clz64(u64 v) { return v ? __builtin_clzll(v) : 64; }
 inline int delta2p(const u32* k, u32 i, u32 j) {
     return (k[i] == k[j]) ? clz64(aug(k, (int)i) ^ aug(k, (int)j)) : clz32(k[i] ^ k[j]);
 }
+
+// ---- the same two questions for u64 keys (60-bit codes): the augmented key {key, position} has 96 bits
+struct Dist96 { u64 hi; u32 lo; };                                          // xor of two augmented keys
+inline bool operator<(const Dist96& a, const Dist96& b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
+inline u64 xdist(const u32* k, int i, int j) { return aug(k, i) ^ aug(k, j); }
+inline Dist96 xdist(const u64* k, int i, int j) { return { k[i] ^ k[j], (u32)i ^ (u32)j }; }
+inline u64 far_dist(const u32*) { return ~0ull; }
+inline Dist96 far_dist(const u64*) { return { ~0ull, ~0u }; }
+inline int delta2p(const u64* k, u32 i, u32 j) { return (k[i] == k[j]) ? 64 + clz32(i ^ j) : clz64(k[i] ^ k[j]); }
 
 // canonical (numbering-independent) topology hash: leaf -> mix(prim), internal -> mix(h(left), h(right)) (ordered)
 inline u64 mix64(u64 x) { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return x; }
@@ -242,6 +301,20 @@ void orc_morton_codes(const void* boxes, u32 stride_bytes, u32 box_offset_bytes,
     }
 }
 
+// u64 keys with a total_bits budget (30 reproduces orc_morton_codes)
+void orc_morton_codes64(const void* boxes, u32 stride_bytes, u32 box_offset_bytes, u32 n, const void* scene, int total_bits, u64* keys_out) {
+    const Box* s = (const Box*)scene;
+    const F3 e = { s->hi.x - s->lo.x, s->hi.y - s->lo.y, s->hi.z - s->lo.z };
+    const MortonPlan m = morton_plan(e, (u32)total_bits);
+    const char* base = (const char*)boxes + box_offset_bytes;
+    for (u32 i = 0; i < n; ++i) {
+        Box b; std::memcpy(&b, base + (size_t)i * stride_bytes, sizeof(Box));
+        const F3 c = { (b.hi.x + b.lo.x) * 0.5f, (b.hi.y + b.lo.y) * 0.5f, (b.hi.z + b.lo.z) * 0.5f };
+        const float p[3] = { (c.x - s->lo.x) / e.x, (c.y - s->lo.y) / e.y, (c.z - s->lo.z) / e.z };
+        keys_out[i] = morton_encode64(m, p);
+    }
+}
+
 // ---- Stage S: contract adopted for Oro::RadixSort::sort(src,dst,n,0,32) (call sites src/TwoPassLbvh.cpp:71-89 ...):
 // stable ascending on the full 32-bit key.  parity unpinned on the reference side (implementation not in tree).
 void orc_sort_pairs(const u32* keys, const u32* vals, u32 n, u32* skeys, u32* svals) {
@@ -254,7 +327,9 @@ void orc_sort_pairs(const u32* keys, const u32* vals, u32 n, u32* skeys, u32* sv
 // ---- B-1p: Apetrei single-pass LBVH.  src/SinglePassLbvhKernel.h:27-126.  nodes_out: Node2[2n-1]; returns root index.
 // Serial execution of the per-leaf walkers is one legal schedule of the kernel; the second-arriver rule makes the
 // result schedule independent.
-u32 orc_lbvh_single(const void* tris, u32 n, const u32* skeys, const u32* svals, void* nodes_out) {
+}  // extern "C"
+template <typename K>
+static u32 lbvh_single_impl(const void* tris, u32 n, const K* skeys, const u32* svals, void* nodes_out) {
     const Tri* t = (const Tri*)tris; Node2* nd = (Node2*)nodes_out;
     const u32 ni = n - 1;
     for (u32 g = 0; g < n; ++g) {                              // InitBvhNodes :27-54
@@ -264,9 +339,9 @@ u32 orc_lbvh_single(const void* tris, u32 n, const u32* skeys, const u32* svals,
     if (n == 1) return 0;   // kernel: findParent(0,1,1) == INVALID; counter[INVALID] UB in the reference; define root = the leaf
     std::vector<int> counter(n, 0);
     std::vector<u32> span_lo(n, 0), span_hi(n, 0);
-    auto hdb = [&](int i, int j) -> u64 {                     // findHighestDiffBit :56-62
-        if (j < 0 || j >= (int)n) return ~0ull;
-        return aug(skeys, i) ^ aug(skeys, j);
+    auto hdb = [&](int i, int j) {                            // findHighestDiffBit :56-62 (u32 keys: xor of the 64-bit augmented keys)
+        if (j < 0 || j >= (int)n) return far_dist(skeys);
+        return xdist(skeys, i, j);
     };
     auto find_parent = [&](u32 cur, int i, int j) -> u32 {    // findParent :64-86
         if (i == 0 && j == (int)n) return INV;
@@ -285,10 +360,15 @@ u32 orc_lbvh_single(const void* tris, u32 n, const u32* skeys, const u32* svals,
     }
     return root;
 }
+extern "C" {
+u32 orc_lbvh_single(const void* tris, u32 n, const u32* skeys, const u32* svals, void* nodes_out) { return lbvh_single_impl<u32>(tris, n, skeys, svals, nodes_out); }
+u32 orc_lbvh_single64(const void* tris, u32 n, const u64* skeys, const u32* svals, void* nodes_out) { return lbvh_single_impl<u64>(tris, n, skeys, svals, nodes_out); }
 
 // ---- B-2p: Karras two-pass LBVH.  src/TwoPassLbvhKernel.h:42-130,164-235.  refs: Leaf[n] (PrimRef); nodes_out Node2[2n-1];
 // parents_out (optional) u32[2n-1].  Root is node 0.
-void orc_lbvh_two(const void* refs, u32 n, const u32* k, const u32* svals, void* nodes_out, u32* parents_out) {
+}  // extern "C"
+template <typename K>
+static void lbvh_two_impl(const void* refs, u32 n, const K* k, const u32* svals, void* nodes_out, u32* parents_out) {
     const Leaf* pr = (const Leaf*)refs; Node2* nd = (Node2*)nodes_out;
     const u32 ni = n - 1;
     std::vector<u32> parent(2 * (size_t)n - 1, INV);
@@ -337,6 +417,9 @@ void orc_lbvh_two(const void* refs, u32 n, const u32* k, const u32* svals, void*
         }
     if (parents_out) std::memcpy(parents_out, parent.data(), parent.size() * 4);
 }
+extern "C" {
+void orc_lbvh_two(const void* refs, u32 n, const u32* k, const u32* svals, void* nodes_out, u32* parents_out) { lbvh_two_impl<u32>(refs, n, k, svals, nodes_out, parents_out); }
+void orc_lbvh_two64(const void* refs, u32 n, const u64* k, const u32* svals, void* nodes_out, u32* parents_out) { lbvh_two_impl<u64>(refs, n, k, svals, nodes_out, parents_out); }
 
 // ---- statistics block shared by the PLOC-family emitters (feeds DESIGN.md's algorithmic-bytes figures)
 struct OrcStats { u64 iterations, cluster_loads, cluster_stores, merge_calls, nn_rounds; };
@@ -429,7 +512,9 @@ void orc_ploc(const void* boxes, u32 n, const u32* svals, void* nodes_out, void*
 // The 32-slot work list models the reference's wave32 LDS arrays (WarpSize = 32 on this target, src/Common.h:100-106).
 // Compaction is modelled as "valid lanes write to their rank, slot[count] = INVALID" — the outcome of :183-185 when the
 // highest lane's store wins.
-void orc_hploc(const void* boxes, u32 n, const u32* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) {
+}  // extern "C"
+template <typename K>
+static void hploc_impl(const void* boxes, u32 n, const K* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) {
     const Box* pb = (const Box*)boxes; Node2* nd = (Node2*)nodes_out; Leaf* lf = (Leaf*)leaves_out;
     const u32 ni = n - 1;
     OrcStats st = {0, 0, 0, 0, 0};
@@ -440,9 +525,9 @@ void orc_hploc(const void* boxes, u32 n, const u32* skeys, const u32* svals, voi
     }
     constexpr int W = 32, HALF = 16, RAD = 8;
     u32 allocated = 0;                                         // *nMergedClusters
-    auto hdb = [&](int i, int j) -> u64 {                     // :58-64
-        if (i < 0 || j >= (int)n) return ~0ull;
-        return aug(skeys, i) ^ aug(skeys, j);
+    auto hdb = [&](int i, int j) {                            // :58-64
+        if (i < 0 || j >= (int)n) return far_dist(skeys);
+        return xdist(skeys, i, j);
     };
     auto find_parent = [&](int i, int j) -> u32 {             // :66-81 (j inclusive; the j==n tests never fire)
         if (i == 0 && j == (int)n) return INV;
@@ -518,6 +603,9 @@ void orc_hploc(const void* boxes, u32 n, const u32* skeys, const u32* svals, voi
     }
     if (stats_out) std::memcpy(stats_out, &st, sizeof st);
 }
+extern "C" {
+void orc_hploc(const void* boxes, u32 n, const u32* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) { hploc_impl<u32>(boxes, n, skeys, svals, nodes_out, leaves_out, stats_out); }
+void orc_hploc64(const void* boxes, u32 n, const u64* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) { hploc_impl<u64>(boxes, n, skeys, svals, nodes_out, leaves_out, stats_out); }
 
 // ---- SAH cost, BVH2.  Formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349): 1 + sum over internal nodes of both
 // child areas / rootArea + sum over leaves of area / rootArea.  Returned in f64 (order independent to ~1e-12) and, through

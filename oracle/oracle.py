@@ -50,6 +50,10 @@ def lib() -> C.CDLL:
         L.orc_morton_plan.argtypes = [vp, vp]
         L.orc_morton_codes.argtypes = [vp, u32, u32, u32, vp, vp, vp]
         L.orc_sort_pairs.argtypes = [vp, vp, u32, vp, vp]
+        L.orc_morton_codes64.argtypes = [vp, u32, u32, u32, vp, C.c_int, vp]
+        L.orc_lbvh_single64.argtypes = [vp, u32, vp, vp, vp]; L.orc_lbvh_single64.restype = u32
+        L.orc_lbvh_two64.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.orc_hploc64.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         L.orc_lbvh_single.argtypes = [vp, u32, vp, vp, vp]; L.orc_lbvh_single.restype = u32
         L.orc_lbvh_two.argtypes = [vp, u32, vp, vp, vp, vp]
         L.orc_ploc.argtypes = [vp, u32, vp, vp, vp, vp]
@@ -101,18 +105,31 @@ def morton_codes(boxes: np.ndarray, scene: np.ndarray):
     return keys, vals
 
 
+def morton_codes64(boxes: np.ndarray, scene: np.ndarray, total_bits: int = 60) -> np.ndarray:
+    """u64 extended Morton codes with a total_bits budget (30 reproduces morton_codes)"""
+    n = boxes.shape[0]
+    keys = np.empty(n, dtype=np.uint64)
+    lib().orc_morton_codes64(boxes.ctypes.data, boxes.dtype.itemsize, 0, n, scene.ctypes.data, total_bits, keys.ctypes.data)
+    return keys
+
+
 def sort_pairs(keys: np.ndarray, vals: np.ndarray | None = None):
+    if keys.dtype == np.uint64:      # the adopted contract, on u64 keys: stable ascending
+        order = np.argsort(keys, kind="stable").astype(np.uint32)
+        return keys[order], (order if vals is None else vals[order])
     n = keys.shape[0]
     sk = np.empty(n, dtype=np.uint32); sv = np.empty(n, dtype=np.uint32)
     lib().orc_sort_pairs(keys.ctypes.data, _p(vals), n, sk.ctypes.data, sv.ctypes.data)
     return sk, sv
 
 
-def front_end(tris: np.ndarray):
-    """E + M + S -> dict(boxes, scene, keys, skeys, svals)"""
+def front_end(tris: np.ndarray, morton_bits: int = 30):
+    """E + M + S -> dict(boxes, scene, keys, skeys, svals); morton_bits 60: u64 keys"""
     boxes, scene = prim_bounds(tris)
-    keys, vals = morton_codes(boxes, scene)
-    sk, sv = sort_pairs(keys, vals)
+    if morton_bits == 60:
+        keys = morton_codes64(boxes, scene, 60); sk, sv = sort_pairs(keys)
+    else:
+        keys, vals = morton_codes(boxes, scene); sk, sv = sort_pairs(keys, vals)
     return {"boxes": boxes, "scene": scene, "keys": keys, "skeys": sk, "svals": sv}
 
 
@@ -120,7 +137,8 @@ def front_end(tris: np.ndarray):
 def lbvh_single(tris, skeys, svals):
     n = tris.shape[0]
     nodes = np.zeros(2 * n - 1, dtype=BVH2_NODE)
-    root = lib().orc_lbvh_single(tris.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data)
+    fn = lib().orc_lbvh_single64 if skeys.dtype == np.uint64 else lib().orc_lbvh_single
+    root = fn(tris.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data)
     return nodes, int(root)
 
 
@@ -129,7 +147,8 @@ def lbvh_two(tris, skeys, svals):
     refs = primrefs(tris)
     nodes = np.zeros(2 * n - 1, dtype=BVH2_NODE)
     parents = np.empty(2 * n - 1, dtype=np.uint32)
-    lib().orc_lbvh_two(refs.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, parents.ctypes.data)
+    fn = lib().orc_lbvh_two64 if skeys.dtype == np.uint64 else lib().orc_lbvh_two
+    fn(refs.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, parents.ctypes.data)
     return nodes, parents
 
 
@@ -143,13 +162,14 @@ def ploc(boxes, svals):
 def hploc(boxes, skeys, svals):
     n = boxes.shape[0]
     nodes = np.zeros(n - 1, dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); st = np.zeros(1, dtype=STATS)
-    lib().orc_hploc(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, st.ctypes.data)
+    fn = lib().orc_hploc64 if skeys.dtype == np.uint64 else lib().orc_hploc
+    fn(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, st.ctypes.data)
     return nodes, leaves, {k: int(st[k][0]) for k in STATS.names}
 
 
-def build_tree(algo: int, tris: np.ndarray) -> dict:
+def build_tree(algo: int, tris: np.ndarray, morton_bits: int = 30) -> dict:
     """Whole pipeline on the CPU.  algo: 0 two-pass, 1 single-pass, 2 PLOC++, 3 HPLOC."""
-    fe = front_end(tris)
+    fe = front_end(tris, morton_bits)
     out = dict(fe)
     if algo == 1:
         nodes, root = lbvh_single(tris, fe["skeys"], fe["svals"]); out.update(nodes=nodes, leaves=None, root=root, layout=0)
