@@ -370,15 +370,16 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const int p = (int)pc;
             const K kp = wkey(p);
             const int c0 = plen(kp, (u32)p, wkey(p + 1), (u32)p + 1u);
-            auto inside = [&](int j) -> bool { return j >= jmin && j <= jmax && plen(wkey(j), (u32)j, kp, (u32)p) >= c0; };
-            int step = 1;
-            while (inside(p - step)) step <<= 1;
-            int lo = p - (step >> 1);
-            for (int t = step >> 2; t > 0; t >>= 1) if (inside(lo - t)) lo -= t;
-            step = 1;
-            while (inside(p + 1 + step)) step <<= 1;
-            int hi = p + 1 + (step >> 1);
-            for (int t = step >> 2; t > 0; t >>= 1) if (inside(hi + t)) hi += t;
+            auto inside = [&](int j) -> bool { return plen(wkey(j), (u32)j, kp, (u32)p) >= c0; };
+            // the positions sharing the node's prefix are contiguous around p: plain binary searches over the window for the two
+            // ends (a fixed ~log2(T) probes per side; an exponential search costs the wave its longest lane: ~2x as many)
+            int lo = p, hi = p + 1;
+            {   int a = jmin, b = p;                                             // first inside position in [jmin, p]
+                while (a < b) { const int mid = (a + b) >> 1; if (inside(mid)) b = mid; else a = mid + 1; }
+                lo = a; }
+            {   int a = p + 1, b = jmax;                                         // last inside position in [p+1, jmax]
+                while (a < b) { const int mid = (a + b + 1) >> 1; if (inside(mid)) a = mid; else b = mid - 1; }
+                hi = a; }
             const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
             m_range[k] = ext ? M_EXT : 0u;
             if (!ext && (u32)(hi - lo + 1) > HP_HALF) {
