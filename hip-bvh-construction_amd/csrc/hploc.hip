@@ -581,9 +581,11 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
+    const char* ge = getenv("BVH_HPX_GRID");           // (measurements only)
+    const u32 xg = ge ? (u32)atoi(ge) : 2048u;          // multiple of 16: waves are dealt to the 64 sub-queues round-robin
     if (key_bits == 64) hipLaunchKernelGGL(k_hploc_ext<u64>, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
                        (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
-    else                hipLaunchKernelGGL(k_hploc_ext<u32>, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
+    else                hipLaunchKernelGGL(k_hploc_ext<u32>, dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
                        (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
 }
 

@@ -1,8 +1,17 @@
+#!/bin/bash
+# Round profile of the bench command on the GPU box (run through gpurun from the repo root): rocprofv3 kernel trace + stats, then
+# PMC passes in separate runs (FETCH_SIZE, WRITE_SIZE, SQ counters — never combined with tracing flags), summarised into
+# gpurun_out/prof_round/*.md and pmc_traffic.json.  Copy what is to be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/p2
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p2/stats -- python $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 > $R/gpurun_out/p2/bench_stats.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $R/gpurun_out/p2/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-kernel-events > $R/gpurun_out/p2/pmc_sq.log 2>&1
-for d in stats pmc_sq; do f=$(find $R/gpurun_out/p2/$d -name "*.db" | head -1); python $R/tools/rocpd_summary.py $f > $R/gpurun_out/p2/$d.md 2>&1; done
-find $R/gpurun_out/p2 -name "*.db" -size +20M -delete
-tail -3 $R/gpurun_out/p2/bench_stats.log
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round
+rm -rf $O; mkdir -p $O
+python $R/bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 > $O/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $O/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events > $O/pmc_sq.log 2>&1
+for d in stats pmc_sq; do f=$(find $O/$d -name "*.db" | head -1); python $R/tools/rocpd_summary.py $f > $O/$d.md 2>&1; done
+ff=$(find $O/pmc_fetch -name "*.db" | head -1); fw=$(find $O/pmc_write -name "*.db" | head -1)
+python $R/tools/pmc_traffic.py $ff $fw 5 10000000 $O/pmc_traffic.json > $O/traffic.md 2>&1     # 5 builds per PMC run: 1 warm-up + 3 timed + 1 stage-timed
+find $O -name "*.db" -size +16M -delete
+tail -c 600 $O/bench.json
