@@ -47,7 +47,7 @@ struct bvh_ctx {
     SortScratch sort{};
     bvh2_node* nodes = nullptr;       // 2*cap
     bvh_primref* leaves = nullptr;    // cap
-    u64* slots = nullptr;             // cap           (single-pass LBVH hand-off words)
+    u64* slots = nullptr;             // cap           (u64 scratch: BVH4 collapse task queue)
     u32* parent = nullptr;            // 2*cap         (two-pass parent pointers / HPLOC parentIdx)
     u32* flags = nullptr;             // cap           (two-pass refit flags)
     HplocScratch hploc{};             //               (hploc.dep is zeroed when the arena is allocated and stays clean)
@@ -104,7 +104,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->hploc.queue_capacity = hploc_queue_capacity(cap);
     c->hploc.queue_pc = k.take<u32>(c->hploc.queue_capacity);
     c->hploc.queue_rng = k.take<u64>(c->hploc.queue_capacity);
-    c->hploc.queue_count = k.take<u32>(64 * 32);
+    c->hploc.queue_count = k.take<u32>(64 * 32 + 32);      // (+ one word: sub-queue capacity for the LBVH tile scheduler)
     c->ploc.list0 = k.take<uint4>(2 * n);
     c->ploc.list1 = k.take<uint4>(2 * n);
     c->ploc.ids1 = k.take<u32>(n);
@@ -308,7 +308,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->slots, c->small);
+    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count);
     HIP_TRY(hipGetLastError());
     if (root_out) { HIP_TRY(hipMemcpyAsync(root_out, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return 0;
@@ -368,7 +368,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     // B: hierarchy emit (token BvhBuildTime; SetupClusters is booked here, not under Morton as the reference does)
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
     switch (algo) {
-        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->slots, c->small); break;
+        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags); break;
         case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves);
                                   out->d_leaves = c->leaves; out->layout = 1; break;

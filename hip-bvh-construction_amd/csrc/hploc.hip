@@ -577,6 +577,15 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
     { KernelScope ks(s, "k_hploc_block");
       if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC);
       else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, 6);
+#ifdef HPB_EXPERIMENTS
+      else if (t == 768 && nt == 256 && occ == 5) HPB_LAUNCH(u32, 768, 256, 5);
+      else if (t == 768 && nt == 256 && occ == 6) HPB_LAUNCH(u32, 768, 256, 6);
+      else if (t == 1024 && nt == 256 && occ == 4) HPB_LAUNCH(u32, 1024, 256, 4);
+      else if (t == 512 && nt == 256 && occ == 6) HPB_LAUNCH(u32, 512, 256, 6);
+      else if (t == 512 && nt == 256 && occ == 5) HPB_LAUNCH(u32, 512, 256, 5);
+      else if (t == 512 && nt == 128 && occ == 7) HPB_LAUNCH(u32, 512, 128, 7);
+      else if (t == 384 && nt == 128 && occ == 7) HPB_LAUNCH(u32, 384, 128, 7);
+#endif
       else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC); }
 #undef HPB_LAUNCH
     if (dbg) return;

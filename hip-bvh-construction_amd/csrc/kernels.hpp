@@ -60,8 +60,11 @@ void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in,
 
 // ---- stage B (lbvh.hip, hploc.hip, ploc.hip)
 // key_bits: 32 = u32 sorted keys (30-bit Morton codes, the reference), 64 = u64 sorted keys (60-bit codes)
+// d_slots: u64[n] hand-off words, all-zero before the call and left all-zero (self-cleaning).  d_queue / d_queue_count: scratch of the
+// tile scheduler used for large n (uint4[lbvh_queue_capacity(n)], u32[64 * 32]); pass d_queue = nullptr to force the one-launch kernel.
+size_t lbvh_queue_capacity(uint32_t n);
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root);
+                        void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count);
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
 // HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.

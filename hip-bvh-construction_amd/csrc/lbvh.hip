@@ -9,13 +9,17 @@
 // walker may read inside the launch is written with agent-scope write-through stores and read with agent-scope loads; the
 // producer drains its stores (s_waitcnt vmcnt(0)) before the agent-scope RMW that publishes it.  No __threadfence():
 // the reference's two fences per level (src/SinglePassLbvhKernel.h:107,124) would each write back / invalidate a cache.
+#include <cstdlib>
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace bvh {
 
 constexpr int LBVH_BLOCK = 256;
-constexpr u64 SLOT_EMPTY = ~0ull;
+// hand-off words: 0 = empty; {node index + 1, far end of the range}.  The second arriver resets the word, so the array is
+// all-zero again after every completed build (it is zeroed once, when the arena is allocated) — no per-build memset.
+constexpr u64 SLOT_EMPTY = 0ull;
+__device__ __forceinline__ u64 slot_word(u32 node, u32 far) { return ((u64)(node + 1u) << 32) | far; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Single pass.  One walker per leaf.  A finished node covering sorted positions [i,j) chooses its parent exactly as
@@ -25,6 +29,31 @@ constexpr u64 SLOT_EMPTY = ~0ull;
 // the first arriver leaves {its node index, the far end of its range} and retires; the second arriver receives it, so it
 // knows both children and the parent's full range, reads the sibling's box, and writes the parent node once (32 B).
 // ------------------------------------------------------------------------------------------------------------------
+constexpr u32 LBQ_SUB = 64;        // sub-queues of the block kernel's hand-over (one atomic per block per launch)
+
+// the climb of one walker whose finished node `cur` (box `box`, already in memory) covers sorted positions [i, j)
+template <typename K>
+__device__ __forceinline__ void lbvh_climb(u32 i, u32 j, u32 cur, Box box, const K* __restrict__ skeys, bvh2_node* nodes, u64* slots, u32* root_out, u32 n) {
+    while (true) {
+        if (i == 0 && j == n) { *root_out = cur; break; }   // :73 -> root (:116-120)
+        bool as_left;
+        if (i == 0) as_left = true;
+        else if (j == n) as_left = false;
+        else as_left = closer(skeys, j - 1, i - 1);
+        const u32 p = as_left ? j - 1 : i - 1;
+        drain_stores();                                     // my node is in memory before anybody can learn its index
+        const u64 other = __hip_atomic_exchange(slots + p, slot_word(cur, as_left ? i : j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other == SLOT_EMPTY) break;                     // first arriver retires (atomicAdd(...) > 0 fails, :103)
+        st_agent(slots + p, SLOT_EMPTY);                    // nobody touches this word again: leave it clean for the next build
+        compiler_fence();
+        const u32 sib = (u32)(other >> 32) - 1u, far = (u32)other;
+        box = box_union(box, node_box_agent(nodes + sib));  // merge(left.aabb, right.aabb) (:112) — min/max commute
+        node_store_agent(nodes + p, as_left ? cur : sib, as_left ? sib : cur, box);
+        if (as_left) j = far; else i = far;
+        cur = p;
+    }
+}
+
 template <typename K>
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                             const u32* __restrict__ svals, bvh2_node* nodes, u64* slots,
@@ -35,24 +64,106 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
     const u32 prim = svals[g];
     Box box = box_load(boxes + prim);                       // = bounds of Triangle[prim] (:44), computed once in stage E
     node_store_agent(nodes + ni + g, prim, INV, box);       // leaf record {left = primIdx, right = INVALID} (:36-45)
-    u32 i = g, j = g + 1, cur = ni + g;
-    while (true) {
-        if (i == 0 && j == n) { *root_out = cur; break; }   // :73 -> root (:116-120)
-        bool as_left;
-        if (i == 0) as_left = true;
-        else if (j == n) as_left = false;
-        else as_left = closer(skeys, j - 1, i - 1);
-        const u32 p = as_left ? j - 1 : i - 1;
-        const u64 mine = ((u64)cur << 32) | (as_left ? i : j);
-        drain_stores();                                     // my node is in memory before anybody can learn its index
-        const u64 other = __hip_atomic_exchange(slots + p, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (other == SLOT_EMPTY) break;                     // first arriver retires (atomicAdd(...) > 0 fails, :103)
-        compiler_fence();
-        const u32 sib = (u32)(other >> 32), far = (u32)other;
-        box = box_union(box, node_box_agent(nodes + sib));  // merge(left.aabb, right.aabb) (:112) — min/max commute
-        node_store_agent(nodes + p, as_left ? cur : sib, as_left ? sib : cur, box);
-        if (as_left) j = far; else i = far;
-        cur = p;
+    lbvh_climb(g, g + 1, ni + g, box, skeys, nodes, slots, root_out, n);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Single pass, large inputs: a workgroup owns a tile of T sorted leaves and builds every node whose range lies inside the tile
+// with the same second-arriver rule, but through LDS (an LDS exchange per node, the first arriver's box parked in LDS): no global
+// atomics, no dependent global loads — the kernel streams {sorted value, box gather} in and {leaf node, internal node} out.  Whether
+// the node of gap p leaves the tile is two key probes (does the leaf just outside the tile share p's prefix?).  The subtree roots
+// whose parent leaves the tile (the ancestors of the T-aligned gaps: ~4 % of the nodes) are queued; k_lbvh_ext continues their
+// climb with the global protocol above.  Node index = split position, as before: the array is byte-identical.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename K, int T>
+__global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
+                                                  const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
+                                                  uint4* __restrict__ queue, u32* __restrict__ queue_count, u32 q_cap, u32* root_out, u32 n) {
+    __shared__ K s_key[T + 2];                       // sorted keys of positions g0-1 .. g0+T
+    __shared__ u64 s_slot[T];                        // per gap: hand-off word of the first arriver (slot_word), 0 = nobody yet
+    __shared__ float s_lbox[6][T];                   // boxes of the tile's leaves
+    __shared__ float s_nbox[6][T];                   // boxes of the tile's finished internal nodes (written once, by their creator)
+    __shared__ unsigned char s_ext[T];               // per gap: the node's range leaves the tile
+    __shared__ u64 s_q[T];                           // subtree roots handed to k_lbvh_ext: {node : 32 | i - g0 : 16 | j - g0 : 16}
+    __shared__ u32 s_nq, s_qbase;
+    const int tid = threadIdx.x;
+    const u32 ni = n - 1;
+    const u32 g0 = blockIdx.x * (u32)T, g = g0 + (u32)tid;
+    const u32 t_end = (g0 + (u32)T < n) ? g0 + (u32)T : n;            // the tile's leaves: [g0, t_end)
+    for (int k = tid; k < T + 2; k += T) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
+    s_slot[tid] = 0ull;
+    if (tid == 0) s_nq = 0u;
+    Box box = box_empty();
+    if (g < n) {
+        const u32 prim = svals[g];
+        box = box_load(boxes + prim);                                     // = bounds of Triangle[prim] (:44), computed once in stage E
+        node_store_plain(nodes + ni + g, prim, INV, box);                 // leaf record (:36-45); read again only by later launches
+        s_lbox[0][tid] = box.lx; s_lbox[1][tid] = box.ly; s_lbox[2][tid] = box.lz; s_lbox[3][tid] = box.hx; s_lbox[4][tid] = box.hy; s_lbox[5][tid] = box.hz;
+    }
+    __syncthreads();
+    auto wkey = [&](u32 j) -> K { return s_key[j - g0 + 1u]; };            // j in [g0-1, g0+T]
+    {   // does the node of gap g leave the tile?  (the positions sharing its prefix are contiguous: probe the first leaf outside)
+        bool ext = true;                                                  // the tile's last gap belongs to two tiles
+        if (g + 1u < t_end) {
+            const K kp = wkey(g);
+            const int c0 = plen(kp, g, wkey(g + 1u), g + 1u);
+            ext = (g0 > 0u && plen(wkey(g0 - 1u), g0 - 1u, kp, g) >= c0) || (t_end < n && plen(wkey(t_end), t_end, kp, g) >= c0);
+        }
+        s_ext[tid] = ext ? 1 : 0;
+    }
+    __syncthreads();
+    if (g < n) {
+        u32 i = g, j = g + 1u, cur = ni + g;                              // finished node `cur` covers sorted positions [i, j)
+        while (true) {
+            if (i == 0u && j == n) { *root_out = cur; break; }            // (single-tile input)
+            bool as_left;                                                 // findParent (:64-86); plen comparison == closer()
+            if (i == 0u) as_left = true;
+            else if (j == n) as_left = false;
+            else as_left = plen(wkey(j - 1u), j - 1u, wkey(j), j) > plen(wkey(i - 1u), i - 1u, wkey(i), i);
+            const u32 p = as_left ? j - 1u : i - 1u;
+            if (p < g0 || s_ext[p - g0]) {                                // parent leaves the tile: hand the subtree root over
+                s_q[atomicAdd(&s_nq, 1u)] = ((u64)cur << 32) | ((u64)(i - g0) << 16) | (u64)(j - g0);
+                break;
+            }
+            const u32 ps = p - g0;
+            const u64 other = atomicExch(reinterpret_cast<unsigned long long*>(&s_slot[ps]), (unsigned long long)slot_word(cur, as_left ? i : j));
+            if (other == SLOT_EMPTY) break;                               // first arriver retires (its box is parked in LDS already)
+            const u32 sib = (u32)(other >> 32) - 1u, far = (u32)other;
+            const bool sl = sib >= ni;                                    // sibling is a leaf / an internal node of this tile
+            const u32 ss = sl ? sib - ni - g0 : sib - g0;
+            const Box sb = sl ? Box{ s_lbox[0][ss], s_lbox[1][ss], s_lbox[2][ss], s_lbox[3][ss], s_lbox[4][ss], s_lbox[5][ss] }
+                              : Box{ s_nbox[0][ss], s_nbox[1][ss], s_nbox[2][ss], s_nbox[3][ss], s_nbox[4][ss], s_nbox[5][ss] };
+            box = box_union(box, sb);                                     // merge(left.aabb, right.aabb) (:112) — min/max commute
+            node_store_plain(nodes + p, as_left ? cur : sib, as_left ? sib : cur, box);
+            // park the new node's box before its own hand-off (LDS operations of a wave execute in order)
+            s_nbox[0][ps] = box.lx; s_nbox[1][ps] = box.ly; s_nbox[2][ps] = box.lz; s_nbox[3][ps] = box.hx; s_nbox[4][ps] = box.hy; s_nbox[5][ps] = box.hz;
+            if (as_left) j = far; else i = far;
+            cur = p;
+        }
+    }
+    __syncthreads();
+    const u32 nq = s_nq;
+    if (nq) {
+        if (tid == 0) s_qbase = atomicAdd(queue_count + (blockIdx.x % LBQ_SUB) * 32u, nq);
+        __syncthreads();
+        const size_t base = (size_t)(blockIdx.x % LBQ_SUB) * (size_t)q_cap + s_qbase;
+        for (u32 k = (u32)tid; k < nq; k += (u32)T) {
+            const u64 it = s_q[k];
+            queue[base + k] = make_uint4((u32)(it >> 32), g0 + (u32)((it >> 16) & 0xFFFFu), g0 + (u32)(it & 0xFFFFu), 0u);
+        }
+    }
+}
+
+// the subtree roots queued by k_lbvh_block continue with the global second-arriver protocol
+template <typename K>
+__global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ skeys, bvh2_node* nodes, u64* slots, const uint4* __restrict__ queue,
+                                                         const u32* __restrict__ queue_count, u32 cap, u32* root_out, u32 n) {
+    const u32 sub = blockIdx.y;
+    const u32 total = queue_count[sub * 32u];
+    for (u32 k = blockIdx.x * LBVH_BLOCK + threadIdx.x; k < total; k += gridDim.x * LBVH_BLOCK) {
+        const uint4 it = queue[(size_t)sub * cap + k];
+        const Box box = box_load(&nodes[it.x].aabb);                      // written by k_lbvh_block (previous launch)
+        lbvh_climb(it.y, it.z, it.x, box, skeys, nodes, slots, root_out, n);
     }
 }
 
@@ -134,14 +245,32 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-// key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes)
+// key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes).  d_slots: u64[n], all-zero (kept clean by the
+// protocol).  Large inputs: tile kernel + external climb; d_queue: uint4[queue_capacity], d_queue_count: u32[64 * 32 + 1].
+constexpr int LBVH_TILE = 512;
+constexpr uint32_t LBVH_BLOCK_MIN_N = 500000;      // below: one launch (k_lbvh_single)
+size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, uint64_t* d_slots, uint32_t* d_root) {
-    (void)hipMemsetAsync(d_slots, 0xFF, (size_t)n * sizeof(u64), s);
-    const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    KernelScope ks(s, "k_lbvh_single");
-    if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_single<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
-    else                hipLaunchKernelGGL(k_lbvh_single<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
+                        void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count) {
+    const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
+    const bool block = (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
+    if (!block || !d_queue) {
+        const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
+        KernelScope ks(s, "k_lbvh_single");
+        if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_single<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
+        else                hipLaunchKernelGGL(k_lbvh_single<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
+        return;
+    }
+    const u32 cap = (u32)(queue_capacity / LBQ_SUB);    // per sub-queue
+    (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
+    const u32 tiles = (n + LBVH_TILE - 1) / LBVH_TILE;
+    { KernelScope ks(s, "k_lbvh_block");
+      if (key_bits == 64) hipLaunchKernelGGL((k_lbvh_block<u64, LBVH_TILE>), dim3(tiles), dim3(LBVH_TILE), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n);
+      else                hipLaunchKernelGGL((k_lbvh_block<u32, LBVH_TILE>), dim3(tiles), dim3(LBVH_TILE), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n); }
+    { KernelScope ks(s, "k_lbvh_ext");
+      const dim3 g(32, LBQ_SUB);
+      if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_ext<u64>, g, dim3(LBVH_BLOCK), 0, s, (const u64*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, (const u32*)d_queue_count, cap, d_root, n);
+      else                hipLaunchKernelGGL(k_lbvh_ext<u32>, g, dim3(LBVH_BLOCK), 0, s, (const u32*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, (const u32*)d_queue_count, cap, d_root, n); }
 }
 
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,

@@ -214,9 +214,10 @@ def test_every_small_size(pkg, orc, ctx, mode, monkeypatch):
     """n = 2..70 and a few sizes around the 16/32/64 thresholds and the block scheduler's 512-leaf tile, all four builders, both
     HPLOC schedulers (the block scheduler needs more than two tiles and hands smaller inputs to the asynchronous one)"""
     monkeypatch.setenv("BVH_HPLOC_MODE", mode)
+    monkeypatch.setenv("BVH_LBVH_MODE", "block" if mode == "block" else "single")     # single-pass LBVH: tile scheduler / one-launch kernel
     for n in list(range(2, 71)) + [127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1026, 1535, 1536, 1537, 2047, 2048, 2049, 4097]:
         tris = pkg.meshgen.uniform(n, 1000 + n)
-        for algo in ((0, 1, 2, 3) if mode == "async" else (3,)):
+        for algo in ((0, 1, 2, 3) if mode == "async" else (1, 3)):
             got = pkg.BUILDERS[algo]().build(ctx, tris).download(); ref = orc.build_tree(algo, tris)
             assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0, (n, algo)
             if algo in (0, 1, 2):
