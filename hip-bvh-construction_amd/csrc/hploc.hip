@@ -124,7 +124,9 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
 }
 
 // PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
-// registers (w is updated in place).  Node stores are agent-scope write-through: other workgroups read them later.
+// registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
+// read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
+template <bool AGENT = true>
 __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase) {
         const bool have = w.have, final_ = w.final_;
         u32 id = w.id, rep = w.rep, cnt = w.cnt;
@@ -181,7 +183,7 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
                     }
                     at = 0u;
                 } else if (l == 0u || r == 0u) st_agent(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
-                node_store_agent(nodes + at, l, r, b);
+                if (AGENT) node_store_agent(nodes + at, l, r, b); else node_store_plain(nodes + at, l, r, b);
                 id = at;
             }
             // compaction: survivors and merged clusters keep their order (:176-187 as "valid slots write to their rank").
@@ -297,7 +299,8 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__
 // local task therefore has no global load in front of its PLOC rounds and only the 32-byte node store behind them.
 // Nodes whose range crosses a block boundary ("external": the ancestors of the T-aligned gaps) use the dependency protocol:
 // the block publishes the records of its maximal local ranges and its external nodes' own contributions; nodes completed by
-// that are queued (HPQ_SUB sub-queues, one atomic per block) for k_hploc_ext, which climbs from there.
+// that are queued (HPQ_SUB sub-queues, one atomic per block) for k_hploc_ext, which climbs from there.  Nothing this kernel
+// writes is read before the next launch, so all its stores are plain cached stores and nothing is drained.
 // =====================================================================================================================
 constexpr u32 HPQ_SUB = 64;        // sub-queues (a single queue head would serialise one atomic per block)
 constexpr u32 HPQ_LOCAL = 32;      // ready items a block aggregates in LDS before falling back to one atomic per item
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 w.id = decode_id(e_id[sp]); w.rep = g0 + e_rep[sp];
                 w.b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
             }
-            ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase);
+            ploc_rounds<false>(w, nodes, zero_parent, ni, lane, slot, hbase);
             if (have && slot < 16) {                 // storeIndices (:208-218) into the range's first 16 positions
                 const u32 d = L + (u32)slot;
                 e_id[d] = (unsigned short)(w.id == INV ? 0xFFFFu : (w.id >= ni ? 0x8000u | (w.id - ni - g0) : w.id - g0));
@@ -437,7 +440,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         }
         __syncthreads();
     }
-    drain_stores();                                  // every wave's node stores are in memory before anything is published (step 2)
     if (dbg == 3) return;
 
     // ---- hand-over, step 1 (one thread per gap): an external node adds its own contribution — which children are small, and
@@ -495,10 +497,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 const u32 Lr = rg & 0xFFFFu; L = g0 + Lr; R = g0 + (rg >> 16); right = (tk & 0x8000u) != 0u;
                 const u32 sp = Lr + (u32)sl;
                 const Box b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
-                node_store_agent(recs + L + sl, decode_id(e_id[sp]), g0 + e_rep[sp], b);
+                node_store_plain(recs + L + sl, decode_id(e_id[sp]), g0 + e_rep[sp], b);     // read by k_hploc_ext: the kernel boundary orders it
             }
-            drain_stores();                          // the wave's record (and, earlier, node) stores are in memory ...
-            if (on && sl == 0) {                     // ... before lane 0 of each group publishes
+            if (on && sl == 0) {                     // lane 0 of each group moves the parent's count
                 const u32 q = right ? L - 1u : R;
                 u32 pL, pR;
                 if (dep_arrive(dep, q, right ? dep_word(1u, 0u, R) : dep_word(1u, L, 0u), pL, pR)) ready_push(q, pL, pR);
