@@ -29,12 +29,14 @@ template <typename K> struct PairRec;
 template <> struct PairRec<u32> {
     using type = u64;
     static __device__ __forceinline__ type pack(u32 k, u32 v) { return (u64)k | ((u64)v << 32); }
+    static __device__ __forceinline__ type pad() { return 0xFFFFFFFFull; }                 // key all ones, value 0
     static __device__ __forceinline__ u32 key(type r) { return (u32)r; }
     static __device__ __forceinline__ u32 val(type r) { return (u32)(r >> 32); }
 };
 template <> struct PairRec<u64> {
     using type = uint4;
     static __device__ __forceinline__ type pack(u64 k, u32 v) { return make_uint4((u32)k, (u32)(k >> 32), v, 0u); }
+    static __device__ __forceinline__ type pad() { return make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u); }
     static __device__ __forceinline__ u64 key(type r) { return (u64)r.x | ((u64)r.y << 32); }
     static __device__ __forceinline__ u32 val(type r) { return r.z; }
 };
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
         const u32 local = (u32)(wave * WAVE * SORT_IPT + i * WAVE + lane);
         const bool ok = local < valid;
         if (IN_AOS) {
-            if (ok) { const typename Rec::type kv = reinterpret_cast<const typename Rec::type*>(keys_in)[base + local]; key[i] = Rec::key(kv); val[i] = Rec::val(kv); }
-            else { key[i] = ~(K)0; val[i] = 0u; }
+            const typename Rec::type kv = ok ? reinterpret_cast<const typename Rec::type*>(keys_in)[base + local] : Rec::pad();   // (a select, not a
+            key[i] = Rec::key(kv); val[i] = Rec::val(kv);                                   //  branch: the 16 loads stay in flight together)
         } else {
             key[i] = ok ? keys_in[base + local] : ~(K)0;
             val[i] = IOTA ? (base + local) : (ok ? vals_in[base + local] : 0u);
