@@ -43,8 +43,14 @@
 
 namespace bvh {
 
-// ablation switch for measurements only (results are incomplete when set)
-static inline int hploc_ablation() { const char* e = getenv("BVH_HPLOC_DEBUG"); return e ? atoi(e) : 0; }
+// ablation switch for measurements only (results are incomplete when set): compiled in with -DBVH_ABLATION (tools/build_variant.sh)
+static inline int hploc_ablation() {
+#ifdef BVH_ABLATION
+    const char* e = getenv("BVH_HPLOC_DEBUG"); return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
 
 constexpr int HP_BLOCK = 256;
 constexpr u32 HP_HALF = 16;        // WarpSize/2 of the reference's wave32 (src/HplocKernel.h:195,238)
@@ -560,8 +566,10 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
 #endif
 static void hpb_config(int* t, int* nt, int* occ) {
     *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
+#ifdef BVH_ABLATION
     const char* e = getenv("BVH_HPB");                 // "T,NT,OCC" (measurements only; 1024,512 is the other compiled tile)
     if (e) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { *t = a; *nt = b; *occ = c; } }
+#endif
 }
 uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return (uint32_t)t; }
 // every tile may queue up to 2T nodes (its own external nodes + the parents of its maximal local ones), tiles >= 128 leaves
@@ -578,22 +586,13 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
     { KernelScope ks(s, "k_hploc_block");
       if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC);
       else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, 6);
-#ifdef HPB_EXPERIMENTS
-      else if (t == 768 && nt == 256 && occ == 5) HPB_LAUNCH(u32, 768, 256, 5);
-      else if (t == 768 && nt == 256 && occ == 6) HPB_LAUNCH(u32, 768, 256, 6);
-      else if (t == 1024 && nt == 256 && occ == 4) HPB_LAUNCH(u32, 1024, 256, 4);
-      else if (t == 512 && nt == 256 && occ == 6) HPB_LAUNCH(u32, 512, 256, 6);
-      else if (t == 512 && nt == 256 && occ == 5) HPB_LAUNCH(u32, 512, 256, 5);
-      else if (t == 512 && nt == 128 && occ == 7) HPB_LAUNCH(u32, 512, 128, 7);
-      else if (t == 384 && nt == 128 && occ == 7) HPB_LAUNCH(u32, 384, 128, 7);
-#endif
       else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC); }
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
-    const char* ge = getenv("BVH_HPX_GRID");           // (measurements only)
-    const u32 xg = ge ? (u32)atoi(ge) : 2048u;          // multiple of 16: waves are dealt to the 64 sub-queues round-robin
-    if (key_bits == 64) hipLaunchKernelGGL(k_hploc_ext<u64>, dim3(2048), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
+    const u32 xg = 2048u;                               // 8 waves per SIMD (measured flat from 2048 to 8192 workgroups); a multiple of 16:
+                                                        // waves are dealt to the 64 sub-queues round-robin
+    if (key_bits == 64) hipLaunchKernelGGL(k_hploc_ext<u64>, dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
                        (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
     else                hipLaunchKernelGGL(k_hploc_ext<u32>, dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
                        (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);

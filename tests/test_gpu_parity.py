@@ -226,9 +226,14 @@ def test_every_small_size(pkg, orc, ctx, mode, monkeypatch):
                 assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1), (n, algo)
 
 
-@pytest.mark.parametrize("kind", ["identical", "two_far_clusters", "line", "point_cloud_dups", "huge_and_tiny"])
+@pytest.mark.parametrize("sched", ["default", "block"])
+@pytest.mark.parametrize("kind", ["identical", "two_far_clusters", "line", "point_cloud_dups", "huge_and_tiny", "staircase"])
 @pytest.mark.parametrize("algo", [0, 1, 2, 3])
-def test_degenerate_distributions(pkg, orc, ctx, kind, algo):
+def test_degenerate_distributions(pkg, orc, ctx, kind, algo, sched, monkeypatch):
+    if sched == "block":
+        if algo not in (1, 3):
+            pytest.skip("tile schedulers exist for single-pass LBVH and HPLOC")
+        monkeypatch.setenv("BVH_HPLOC_MODE", "block"); monkeypatch.setenv("BVH_LBVH_MODE", "block")
     mg = pkg.meshgen
     if kind == "identical":            # every Morton key equal: the hierarchy comes from the position bits only
         tris = np.repeat(mg.uniform(1, 3), 3000)
@@ -240,6 +245,11 @@ def test_degenerate_distributions(pkg, orc, ctx, kind, algo):
             tris[v][:, 1] = 0.5; tris[v][:, 2] = -2.0
     elif kind == "point_cloud_dups":   # 64 distinct positions, each 50 times
         tris = np.tile(mg.uniform(64, 7), 50)
+    elif kind == "staircase":          # geometric spacing along a line: the LBVH degenerates into long chains (deep, skewed hierarchy;
+        tris = mg.uniform(6000, 9)     # many nodes cross every tile boundary of the block schedulers)
+        x = (np.float32(2.0) ** (-(np.arange(6000) % 120).astype(np.float32) / 4)) + (np.arange(6000) // 120).astype(np.float32) * np.float32(1e-6)
+        for v in ("v1", "v2", "v3"):
+            tris[v][:, 0] = x; tris[v][:, 1] = 0.0; tris[v][:, 2] = 0.0
     else:                              # one scene-sized triangle among tiny ones (Sponza-like size variance)
         tris = mg.uniform(4000, 8); tris["v1"][0] = (-50, -50, -50); tris["v2"][0] = (60, 0, 0); tris["v3"][0] = (0, 70, 55)
     tris = np.ascontiguousarray(tris); n = len(tris)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# build_variant.sh NAME "EXTRA_FLAGS" — A/B build of the native library into build/variants/libbvh_NAME.so (same ABI; select with
+# build_variant.sh NAME "EXTRA_FLAGS" — A/B build (with -DBVH_ABLATION: the BVH_HPLOC_DEBUG / BVH_HPB / BVH_SORT_DEBUG measurement knobs) of the native library into build/variants/libbvh_NAME.so (same ABI; select with
 # BVH_MI355X_LIB).  Only hploc.hip / sort.hip / lbvh.hip take the extra flags' macros; everything is recompiled in a scratch dir.
 set -e
 NAME=$1; EXTRA=$2
@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/build/variants; OBJ=$ROOT/build/variants/obj_$NAME
 mkdir -p $OBJ
 cd $ROOT/hip-bvh-construction_amd/csrc
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I. -Wno-unused-value -Wno-unused-result -Wno-pass-failed"
+FLAGS="-DBVH_ABLATION -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I. -Wno-unused-value -Wno-unused-result -Wno-pass-failed"
 for f in api stage_em sort misc trace batched; do [ -f $OBJ/$f.o ] && [ $OBJ/$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o $OBJ/$f.o & done
 for f in lbvh hploc ploc collapse; do /opt/rocm/bin/hipcc $FLAGS -fno-honor-nans -mno-amdgpu-ieee $EXTRA -c $f.hip -o $OBJ/$f.o & done
 wait
