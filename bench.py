@@ -36,6 +36,9 @@ KERNEL_BYTES_PER_PRIM = {
     "k_hploc_block": 177.9,       # block-local kernel: SetupClusters 64 + 85 % of HPloc's 134 (the merge tasks whose range lies inside a 512-leaf tile)
     "k_hploc_ext": 20.1,          # the other 15 % of the merge tasks (ranges crossing tiles)
     "k_lbvh_single": 224.0,
+    "k_lbvh_block": 218.2,        # tile scheduler: the 224 of single-pass LBVH by node share — every leaf (R val 4 + gather 64 + W leaf 32 = 100)
+                                  # and 95.3 % of the internal nodes' 124 (keys 4 + R 2 children 64 + W 32 + spans 16 + counter 8)
+    "k_lbvh_ext": 5.8,            # the other 4.7 % of the internal nodes (ranges crossing tiles)
     "k_karras": 100.0, "k_refit": 88.0,
     "k_ploc_iter": 190.0,         # summed over all iterations
 }
