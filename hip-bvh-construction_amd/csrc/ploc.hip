@@ -16,18 +16,19 @@
 
 namespace bvh {
 
-constexpr int PL_BLOCK = 256;
+// workgroup size: 256 threads (4 clusters per thread, 4 workgroups per CU) for the early, bandwidth-bound iterations; 1024 threads (one
+// cluster per thread, the reference's shape) for the late ones, where an iteration is a handful of chunks and its time is one chunk's
+// critical path (measured at 10 M: 22 us per late iteration with 256 threads)
 constexpr int PL_RADIUS = 8;                   // PlocRadius, src/Common.h:595
 constexpr int PL_HALO = 2 * PL_RADIUS;         // :219-221
 constexpr int PL_SPAN = PLOC_CHUNK + 2 * PL_HALO;
-constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
 constexpr u64 PS_LOCAL = 1ull << 62, PS_INCL = 2ull << 62;
 
 struct PlocLds {
     float lx[PL_SPAN], ly[PL_SPAN], lz[PL_SPAN], hx[PL_SPAN], hy[PL_SPAN], hz[PL_SPAN];
     u32 id[PL_SPAN];
     u32 nn[PL_SPAN];        // nearest neighbour, as an index into the span arrays
-    u32 wsum[PL_BLOCK / WAVE];
+    u32 wsum[1024 / WAVE];
     u32 bcast[4];
 };
 
@@ -74,6 +75,7 @@ __device__ __forceinline__ u32 nearest(const PlocLds& s, int k, int lo, int hi) 
 }
 
 // block-wide exclusive scan of a packed {merges<<16 | kept} per-thread count; returns exclusive prefix, total via *total
+template <int PL_BLOCK>
 __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     u32 inc = v;
@@ -90,9 +92,11 @@ __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
 }
 
 // counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
+template <int PL_BLOCK>
 __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
                                                         bvh2_node* __restrict__ nodes,
                                                         u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni) {
+    constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
     __shared__ PlocLds s;
     const u32 C = counts[0];
     if (C <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = C; return; }
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
                     packed += ((u32)mrg[q] << 16) + (u32)keep[q];
                 }
             }
-            u32 tot; u32 ex = block_scan(s, packed, &tot);     // (block_scan's barriers also order the reads above)
+            u32 tot; u32 ex = block_scan<PL_BLOCK>(s, packed, &tot);     // (block_scan's barriers also order the reads above)
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < PL_CPT; ++q) {
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
                 packed += ((u32)mrg[q] << 16) + (u32)keep[q];
             }
         }
-        u32 tot; u32 ex = block_scan(s, packed, &tot);
+        u32 tot; u32 ex = block_scan<PL_BLOCK>(s, packed, &tot);
         // chain the chunk totals: status word {flag:2, merges:31, kept:31}.  Wave 0 walks back 64 predecessors per step
         // (one load per lane, ballot for the nearest inclusive prefix, wave reduction of the aggregates in front of it) —
         // a one-thread walk costs a memory round trip per predecessor, which dominated small scenes.
@@ -245,17 +249,22 @@ void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count
     hipMemsetAsync(sc.status, 0, (size_t)PLOC_MAX_ITERS * ploc_chunks(n) * sizeof(u64), s);
     hipLaunchKernelGGL(k_ploc_init, dim3(1), dim3(64), 0, s, sc.state, count);
 }
-// enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads
+// enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads.  The host does not
+// know the cluster count of an iteration; it only shapes the launch from a guess (C shrinks by ~20 % per iteration): any grid
+// is correct because chunks are taken from a ticket counter, a good guess is merely faster.
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity) {
     (void)d_leaves;
     const u32 chunks = ploc_chunks(n);
-    const u32 grid = chunks < 1024u ? chunks : 1024u;
     u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
     KernelScope ks(s, "k_ploc_iter");                   // the batch of launches is timed as one group
     for (int k = first; k < first + count; ++k) {
         const bool even = ((k + parity) & 1) == 0;
-        hipLaunchKernelGGL(k_ploc_iter, dim3(grid), dim3(PL_BLOCK), 0, s, (const float4*)(even ? sc.list0 : sc.list1), (float4*)(even ? sc.list1 : sc.list0),
-                           (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
+        double guess = (double)chunks; for (int j = 0; j < k; ++j) guess *= 0.83;      // chunks expected at iteration k, generously
+        const bool wide = guess <= 1024.0;                                              // a few workgroups per CU at most: latency matters
+        u32 grid = (u32)(2.0 * guess) + 8u; if (grid > (wide ? 512u : 1024u)) grid = wide ? 512u : 1024u; if (grid > chunks) grid = chunks;
+        const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);
+        if (wide) hipLaunchKernelGGL(k_ploc_iter<1024>, dim3(grid), dim3(1024), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
+        else      hipLaunchKernelGGL(k_ploc_iter<256>,  dim3(grid), dim3(256),  0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
     }
 }
 
