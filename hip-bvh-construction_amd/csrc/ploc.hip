@@ -16,9 +16,15 @@
 
 namespace bvh {
 
-// workgroup size: 256 threads (4 clusters per thread, 4 workgroups per CU) for the early, bandwidth-bound iterations; 1024 threads (one
-// cluster per thread, the reference's shape) for the late ones, where an iteration is a handful of chunks and its time is one chunk's
-// critical path (measured at 10 M: 22 us per late iteration with 256 threads)
+#ifndef PLOC_ABL
+#define PLOC_ABL 0       // measurements only (tools/build_variant.sh): 1 no look-back wait, 2 no NN search, 3 no list stores — results are wrong
+#endif
+// workgroup size: 512 threads (2 clusters per thread, 4 workgroups = 32 waves per CU) for the early, throughput-bound iterations;
+// 1024 threads (one cluster per thread, the reference's shape) for the late ones, where an iteration is a handful of chunks and
+// its time is one chunk's critical path (measured at 10 M: 22 us per late iteration with 256 threads, 8 us with 1024).  Measured
+// at 10 M (whole emit): 128 threads 2.77 ms, 256: 2.20, 512: 2.03, 1024 throughout: 2.22.  Ablations of the first iteration (352 us
+// with 256 threads): waiting for the predecessors' totals in the look-back 131 us, list stores 71 us, nearest-neighbour search 55 us;
+// evaluating each pair once (rows of 56 owned positions + __shfl_up) and a workgroup-wide look-back walk were both slower.
 constexpr int PL_RADIUS = 8;                   // PlocRadius, src/Common.h:595
 constexpr int PL_HALO = 2 * PL_RADIUS;         // :219-221
 constexpr int PL_SPAN = PLOC_CHUNK + 2 * PL_HALO;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
         const int hi = (int)((long long)C - (o - PL_HALO) < PL_SPAN ? (long long)C - (o - PL_HALO) : PL_SPAN);   // one past the last valid
         // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270)
         for (int k = PL_HALO - PL_RADIUS + tid; k < PL_HALO + PLOC_CHUNK + PL_RADIUS; k += PL_BLOCK)
-            if (k >= lo && k < hi) s.nn[k] = nearest(s, k, lo, hi);
+            if (k >= lo && k < hi) s.nn[k] = (PLOC_ABL == 2) ? (u32)(k ^ 1) : nearest(s, k, lo, hi);
         __syncthreads();
         u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
         u32 packed = 0;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
         if (tid < WAVE) {
             const u64 mine = ((u64)(tot >> 16) << 31) | (u64)(tot & 0xFFFFu);
             u64 excl = 0;
-            if (chunk == 0) { if (tid == 0) __hip_atomic_store(status + chunk, PS_INCL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (chunk == 0 || PLOC_ABL == 1) { if (tid == 0) __hip_atomic_store(status + chunk, PS_INCL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else {
                 if (tid == 0) __hip_atomic_store(status + chunk, PS_LOCAL | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 long long hi = (long long)chunk - 1;                       // nearest predecessor not yet accounted for
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
                     id = C - 2 - (m_ex + (ex >> 16));                                                // :311
                     node_store_plain(nodes + id, cid[q], pid[q], cb[q]);
                 }
-                entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);                   // :355-361
+                if (PLOC_ABL != 3) entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);                   // :355-361
             }
             ex += ((u32)mrg[q] << 16) + (u32)keep[q];
         }
@@ -263,8 +269,11 @@ void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_node
         const bool wide = guess <= 1024.0;                                              // a few workgroups per CU at most: latency matters
         u32 grid = (u32)(2.0 * guess) + 8u; if (grid > (wide ? 512u : 1024u)) grid = wide ? 512u : 1024u; if (grid > chunks) grid = chunks;
         const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);
+#ifndef PLOC_NARROW
+#define PLOC_NARROW 512
+#endif
         if (wide) hipLaunchKernelGGL(k_ploc_iter<1024>, dim3(grid), dim3(1024), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
-        else      hipLaunchKernelGGL(k_ploc_iter<256>,  dim3(grid), dim3(256),  0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
+        else      hipLaunchKernelGGL(k_ploc_iter<PLOC_NARROW>,  dim3(grid), dim3(PLOC_NARROW),  0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
     }
 }
 

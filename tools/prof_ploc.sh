@@ -1,0 +1,23 @@
+#!/bin/bash
+# per-launch durations of k_ploc_iter for one PLOC++ build size (rocprofv3 kernel trace): python-side analysis of the rocpd db
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; N=${1:-10000000}
+rocprofv3 --kernel-trace -d $R/gpurun_out/pl -- python $R/bench.py --algo ploc --tris $N --steps 2 --warmup 1 --cpu-sample 0 --no-kernel-events > $R/gpurun_out/pl.log 2>&1
+f=$(find $R/gpurun_out/pl -name "*.db" | head -1)
+python - "$f" <<'PY'
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select name, start, end from kernels order by start").fetchall()
+it = [(s, e) for n, s, e in rows if "k_ploc_iter" in n]
+# last build = last group of launches; split builds by k_ploc_setup
+setups = [s for n, s, e in rows if "k_ploc_setup" in n]
+last = setups[-1]
+it = [(s, e) for s, e in it if s > last]
+print("launches in last build:", len(it))
+t0 = it[0][0]
+for i, (s, e) in enumerate(it):
+    gap = (s - it[i-1][1]) / 1e3 if i else 0.0
+    if i < 50: print(f"iter {i:2d}: dur {(e-s)/1e3:8.1f} us  gap {gap:5.1f} us")
+print("total span %.1f us, sum of durations %.1f us" % ((it[-1][1] - t0) / 1e3, sum(e - s for s, e in it) / 1e3))
+PY
+find $R/gpurun_out/pl -name "*.db" -delete
