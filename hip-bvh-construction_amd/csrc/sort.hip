@@ -125,13 +125,15 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #pragma unroll
     for (int i = 0; i < SORT_IPT; ++i) {
         const u32 d = (u32)(key[i] >> shift) & digit_mask;
-        u64 grp = ~0ull;
+        // lanes whose digit differs from mine in bit b: ballot(bit b) xor (my bit b, sign-extended); the group is what is left
+        u32 diff_lo = 0u, diff_hi = 0u;
 #pragma unroll
         for (int b = 0; b < SORT_BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            grp &= bit ? bal : ~bal;
+            const int mine = __builtin_amdgcn_sbfe((int)d, b, 1);           // 0 or -1
+            const u64 bal = __ballot(mine != 0);
+            diff_lo |= (u32)bal ^ (u32)mine; diff_hi |= (u32)(bal >> 32) ^ (u32)mine;
         }
+        const u64 grp = ~(((u64)diff_hi << 32) | diff_lo);
         const u32 below = (u32)__popcll(grp & lt);
         // every member reads the counter (same address -> LDS broadcast), then the group's lowest lane bumps it; DS
         // operations of a wave execute in order, so the next item's read sees the update without a cross-lane hop
