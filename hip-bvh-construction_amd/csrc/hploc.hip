@@ -64,10 +64,6 @@ __device__ __forceinline__ Box box_shl1(const Box& b) { return { dpp_shl1(b.lx),
 __device__ __forceinline__ Box shfl_box(const Box& b, int src) {
     return { __shfl(b.lx, src), __shfl(b.ly, src), __shfl(b.lz, src), __shfl(b.hx, src), __shfl(b.hy, src), __shfl(b.hz, src) };
 }
-__device__ __forceinline__ float bperm_f32(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
-#ifndef HP_DPP_R
-#define HP_DPP_R 8
-#endif
 // push semantics: lane l's value lands in lane dst(l)
 __device__ __forceinline__ u32 push_u32(int dst, u32 v) { return (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)v); }
 __device__ __forceinline__ float push_f32(int dst, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v))); }
@@ -149,15 +145,27 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             // instead (VALU moves), the rest from the LDS crossbar: the split balances the two pipes
             const int la = lane << 2;
             Box nb = b;
+            // two candidates per step so that the area arithmetic runs as packed f32 (v_pk_add/mul_f32: two lanes of a register pair
+            // per instruction); the min/max of the unions have no packed form.  Same operations, same association, no contraction.
+            typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int r = 1; r <= HP_RADIUS; ++r) {
-                if (r <= HP_DPP_R) nb = box_shl1(nb);                            // box of slot + r
-                else nb = { bperm_f32(la + 4 * r, b.lx), bperm_f32(la + 4 * r, b.ly), bperm_f32(la + 4 * r, b.lz),
-                            bperm_f32(la + 4 * r, b.hx), bperm_f32(la + 4 * r, b.hy), bperm_f32(la + 4 * r, b.hz) };
-                const u32 ab = __float_as_uint(box_area(box_union(nb, b)));
-                const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * r), (int)ab);   // area(slot - r, slot)
-                if ((u32)(slot + r) < cnt && ab < abR) { abR = ab; idR = slot + r; }
-                if (slot >= r && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - r; }
+            for (int r = 1; r <= HP_RADIUS; r += 2) {
+                const Box n1 = box_shl1(nb);                                     // box of slot + r
+                const Box n2 = box_shl1(n1);                                     // box of slot + r + 1
+                nb = n2;
+                const v2f lx = { fminf(n1.lx, b.lx), fminf(n2.lx, b.lx) }, ly = { fminf(n1.ly, b.ly), fminf(n2.ly, b.ly) }, lz = { fminf(n1.lz, b.lz), fminf(n2.lz, b.lz) };
+                const v2f hx = { fmaxf(n1.hx, b.hx), fmaxf(n2.hx, b.hx) }, hy = { fmaxf(n1.hy, b.hy), fmaxf(n2.hy, b.hy) }, hz = { fmaxf(n1.hz, b.hz), fmaxf(n2.hz, b.hz) };
+                const v2f ex = hx - lx, ey = hy - ly, ez = hz - lz;
+                const v2f half_area = ex * ey + ex * ez + ey * ez;               // Aabb::area (:361-365): 2 * (xy + xz + yz)
+                const v2f area = half_area + half_area;                          // (x + x == 2 * x exactly)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int rr = r + q;
+                    const u32 ab = __float_as_uint(q ? area.y : area.x);
+                    const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * rr), (int)ab);   // area(slot - rr, slot)
+                    if ((u32)(slot + rr) < cnt && ab < abR) { abR = ab; idR = slot + rr; }
+                    if (slot >= rr && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - rr; }
+                }
             }
             // mergeClusters (:126-190)
             const int nbr = (abL <= abR) ? idL : idR;
@@ -553,8 +561,8 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
     else                hipLaunchKernelGGL(k_hploc<u32>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
 }
 
-// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  Tile 512 leaves / 256 threads / 7 waves per SIMD
-// (72 VGPRs, no spills; 8 waves spill into scratch) measured best on MI355X: 10 M emit 1.10 ms vs 1.16 (1024/512/6) and 1.24 (256/128).
+// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  Tile 512 leaves / 256 threads / 6 waves per SIMD
+// (80 VGPRs, no spills; 7 waves = 72 VGPRs spill since the rounds evaluate two candidates per step) measured best on MI355X.
 #ifndef HPB_T
 #define HPB_T 512
 #endif
@@ -562,7 +570,7 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
 #define HPB_NT 256
 #endif
 #ifndef HPB_OCC
-#define HPB_OCC 7
+#define HPB_OCC 6
 #endif
 static void hpb_config(int* t, int* nt, int* occ) {
     *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
