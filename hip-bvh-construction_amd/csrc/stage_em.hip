@@ -316,8 +316,11 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
 static inline int em_grid(u32 n) {
-    const u32 blocks = (n + EM_BLOCK - 1) / EM_BLOCK;
-    return (int)(blocks < 2048u ? (blocks ? blocks : 1u) : 2048u);   // 256 CUs x 8 blocks, grid-stride beyond
+    // grid-stride kernels: ~4 primitives per thread up to 2048 workgroups (256 CUs x 8).  Every workgroup ends with global atomics on a
+    // handful of addresses (6 scene-extent words; <= 1024 histogram bins), and one address takes ~90 atomics/us: at 262 k primitives
+    // 1024 one-tile workgroups spent 11 us in that queue (k_extents 31 us, k_morton 23 us), 256 four-tile workgroups do not.
+    const u32 blocks = (n + 4 * EM_BLOCK - 1) / (4 * EM_BLOCK);
+    return (int)(blocks < 2048u ? (blocks ? blocks : 1u) : 2048u);
 }
 
 void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene) {
