@@ -69,8 +69,9 @@ inline bool hploc_use_block(uint32_t n) {
     return n >= HPLOC_BLOCK_MIN_N;
 }
 // HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
-void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves) {
-    if (hploc_use_block(n)) launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc);
+void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves,
+                bool heads_cleared = false) {
+    if (hploc_use_block(n)) launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc, heads_cleared);
     else launch_hploc(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc);
 }
 
@@ -170,13 +171,20 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, const void* d_leaves, const 
 }
 
 // stage E on any of the input formats of bvh_build_input (device pointers)
-int stage_extents_fmt(hipStream_t s, const bvh_build_input* in, uint32_t n, void* d_boxes, void* d_scene) {
+int stage_extents_valid(const bvh_build_input* in) {
     switch (in->tri_format) {
-        case BVH_TRI_PADDED64: if (!in->d_tris) return BVH_E_INVALID_ARG; launch_extents(s, in->d_tris, n, d_boxes, d_scene); return 0;
-        case BVH_TRI_PACKED36: if (!in->d_tris || ((uintptr_t)in->d_tris & 15u)) return BVH_E_INVALID_ARG;      // 16-byte loads
-                               launch_extents_packed(s, in->d_tris, n, d_boxes, d_scene); return 0;
-        case BVH_TRI_INDEXED:  if (!in->d_vertices || !in->d_indices || in->n_vertices == 0) return BVH_E_INVALID_ARG;
-                               launch_extents_indexed(s, in->d_vertices, in->d_indices, in->n_vertices, n, d_boxes, d_scene); return 0;
+        case BVH_TRI_PADDED64: return in->d_tris ? 0 : BVH_E_INVALID_ARG;
+        case BVH_TRI_PACKED36: return (in->d_tris && !((uintptr_t)in->d_tris & 15u)) ? 0 : BVH_E_INVALID_ARG;      // 16-byte loads
+        case BVH_TRI_INDEXED:  return (in->d_vertices && in->d_indices && in->n_vertices) ? 0 : BVH_E_INVALID_ARG;
+        default: return BVH_E_INVALID_ARG;
+    }
+}
+int stage_extents_fmt(hipStream_t s, const bvh_build_input* in, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true) {
+    const int v = stage_extents_valid(in); if (v) return v;
+    switch (in->tri_format) {
+        case BVH_TRI_PADDED64: launch_extents(s, in->d_tris, n, d_boxes, d_scene, reset_scene); return 0;
+        case BVH_TRI_PACKED36: launch_extents_packed(s, in->d_tris, n, d_boxes, d_scene, reset_scene); return 0;
+        case BVH_TRI_INDEXED:  launch_extents_indexed(s, in->d_vertices, in->d_indices, in->n_vertices, n, d_boxes, d_scene, reset_scene); return 0;
         default: return BVH_E_INVALID_ARG;
     }
 }
@@ -354,8 +362,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     // Morton kernel can accumulate the digit histograms.
     const int end_bit = key_bits == 64 ? 60 : 30;              // significant bits of the Morton codes
     const int passes = sort_passes(0, end_bit);
-    sort_prepare(s, c->sort, n, passes);
-    r = stage_extents_fmt(s, in, n, c->boxes, c->scene); if (r) return r;
+    r = stage_extents_valid(in); if (r) return r;
+    sort_prepare(s, c->sort, n, passes, c->scene, c->hploc.queue_count, 64 * 32);    // + Aabb::reset of the scene extent + the emitters' queue heads
+    r = stage_extents_fmt(s, in, n, c->boxes, c->scene, false); if (r) return r;
     if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
     // M: CalculateMortonCodes (token CalculateMortonCodesTime); values are implicit (value i = i), produced by sort pass 0
     if (key_bits == 64) launch_morton64(s, c->boxes, n, c->scene, reinterpret_cast<u64*>(c->keys), 60, c->sort.hist, passes);
@@ -368,9 +377,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     // B: hierarchy emit (token BvhBuildTime; SetupClusters is booked here, not under Morton as the reference does)
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
     switch (algo) {
-        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count); break;
+        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags); break;
-        case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves);
+        case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);
                                   r = run_ploc(c, n, c->nodes, c->leaves, c->ploc, &ploc_iters); if (r) return r;

@@ -584,8 +584,8 @@ uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return 
 size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SUB + 2) * 2 * 128 * HPQ_SUB; }
 
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, void* d_leaves, const HplocScratch& sc) {
-    (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
+                        void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared) {
+    if (!heads_cleared) (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
     int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
     const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);

@@ -21,9 +21,10 @@ struct KernelScope {
 constexpr int EM_BLOCK = 256;
 
 // ---- stage E / M (stage_em.hip)
-void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes, void* d_scene);
-void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene);
-void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene);
+// reset_scene: launch the Aabb::reset of d_scene first (false when sort_prepare already did it)
+void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true);
+void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true);
+void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true);
 void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint32_t* d_keys, uint32_t* d_vals,
                    uint32_t* d_hist /*may be null*/, int hist_bits, int passes);
 // extended Morton code with a 60-bit budget in u64 keys (total_bits = 30 reproduces launch_morton's codes: the parity pin)
@@ -50,8 +51,10 @@ struct SortScratch {
 inline uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 inline int sort_passes(int start_bit, int end_bit) { return (end_bit - start_bit + SORT_BITS - 1) / SORT_BITS; }
 size_t sort_status_bytes(uint32_t n);
-// zero hist/status/counters for `passes` digits (must precede the histogram producer)
-void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes);
+// zero hist/status/counters for `passes` digits (must precede the histogram producer) — one launch that can also reset a scene
+// extent (Aabb::reset) and zero one more small word array
+void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes, float* d_scene_reset = nullptr,
+                  uint32_t* d_extra = nullptr, uint32_t extra_words = 0);
 // hist_ready: sc.hist already holds the per-pass digit counts (fused into the Morton kernel); else a histogram kernel runs.
 void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
                 uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready);
@@ -64,7 +67,8 @@ void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in,
 // tile scheduler used for large n (uint4[lbvh_queue_capacity(n)], u32[64 * 32]); pass d_queue = nullptr to force the one-launch kernel.
 size_t lbvh_queue_capacity(uint32_t n);
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count);
+                        void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count,
+                        bool heads_cleared = false /* d_queue_count is already zero */);
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
 // HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.
@@ -82,7 +86,7 @@ uint32_t hploc_block_tile();
 void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, const HplocScratch& sc);
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, void* d_leaves, const HplocScratch& sc);
+                        void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared = false /* sc.queue_count is already zero */);
 struct PlocScratch {
     void*     list0;         // 32-byte cluster entries {id, box} x n (ping)
     void*     list1;         // pong

@@ -251,7 +251,7 @@ constexpr int LBVH_TILE = 512;
 constexpr uint32_t LBVH_BLOCK_MIN_N = 500000;      // below: one launch (k_lbvh_single)
 size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count) {
+                        void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared) {
     const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
     const bool block = (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
     if (!block || !d_queue) {
@@ -262,7 +262,7 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys,
         return;
     }
     const u32 cap = (u32)(queue_capacity / LBQ_SUB);    // per sub-queue
-    (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
+    if (!heads_cleared) (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
     const u32 tiles = (n + LBVH_TILE - 1) / LBVH_TILE;
     { KernelScope ks(s, "k_lbvh_block");
       if (key_bits == 64) hipLaunchKernelGGL((k_lbvh_block<u64, LBVH_TILE>), dim3(tiles), dim3(LBVH_TILE), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n);

@@ -323,18 +323,18 @@ static inline int em_grid(u32 n) {
     return (int)(blocks < 2048u ? (blocks ? blocks : 1u) : 2048u);
 }
 
-void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene) {
-    hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
+void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene, bool reset_scene) {
+    if (reset_scene) hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
     { KernelScope ks(s, "k_extents"); hipLaunchKernelGGL(k_extents, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n); }
 }
 
-void launch_extents_packed(hipStream_t s, const void* d_tris36, u32 n, void* d_boxes, void* d_scene) {
-    hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
+void launch_extents_packed(hipStream_t s, const void* d_tris36, u32 n, void* d_boxes, void* d_scene, bool reset_scene) {
+    if (reset_scene) hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
     KernelScope ks(s, "k_extents_packed");
     hipLaunchKernelGGL(k_extents_packed, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float*)d_tris36, (bvh_aabb*)d_boxes, (float*)d_scene, n);
 }
-void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, u32 n_vertices, u32 n, void* d_boxes, void* d_scene) {
-    hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
+void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, u32 n_vertices, u32 n, void* d_boxes, void* d_scene, bool reset_scene) {
+    if (reset_scene) hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
     KernelScope ks(s, "k_extents_indexed");
     hipLaunchKernelGGL(k_extents_indexed, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float*)d_vertices, (const u32*)d_indices, n_vertices, (bvh_aabb*)d_boxes, (float*)d_scene, n);
 }
