@@ -61,7 +61,7 @@ EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_build_ex", "bvh_stage_extents", "bvh_stage_extents_ex",
     "bvh_stage_morton", "bvh_stage_morton64", "bvh_sort_pairs", "bvh_sort_pairs64",
-    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_sah_cost",
+    "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_trace", "bvh_sah_cost",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
 
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
         "bvh_batched_build": ([i32, C.POINTER(i32), i32, C.POINTER(vp), C.POINTER(u32), i32, C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "bvh_generate_rays": ([vp, vp, vp, u32, u32], i32),
         "bvh_trace_while": ([vp, vp, vp, vp, u32, u32, vp, vp, u32, u32], i32),
+        "bvh_trace": ([vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, u32, u32], i32),
         "bvh_collapse4": ([vp, C.POINTER(Result), vp, vp, C.POINTER(u32)], i32),
         "bvh_ctx_kernel_times": ([vp, C.c_char_p, u32, C.POINTER(C.c_float), C.POINTER(u32), u32], i32),
         "bvh_version": ([], C.c_char_p),
@@ -328,9 +329,10 @@ class _Builder:
         wide.free(); prims.free()
         return out
 
-    def render(self, tris_host: np.ndarray, camera: np.ndarray, transform: np.ndarray, width: int = 512):
-        """traverseBvh's image: GenerateRays + while-while traversal of this tree (through the LBVH-layout adapter for
-        PLOC/HPLOC).  Returns (rgba uint8[width*width*4], rays RAY[width*width])."""
+    def render(self, tris_host: np.ndarray, camera: np.ndarray, transform: np.ndarray, width: int = 512, kind: int = 0, counts: bool = False):
+        """traverseBvh's image: GenerateRays + traversal of this tree (through the LBVH-layout adapter for PLOC/HPLOC).  kind: 0 while-while,
+        1 restart trail, 2 if-if, 3 speculative while-while.  Returns (rgba uint8[width*width*4], rays RAY[width*width])
+        (+ triangle tests per ray if counts)."""
         ctx, n = self._ctx, self.result.n_leaves
         d_tris = ctx.upload(tris_host)
         d_nodes = ctx.alloc((2 * n - 1) * BVH2_NODE.itemsize)
@@ -338,9 +340,12 @@ class _Builder:
         d_rays = ctx.alloc(width * width * RAY.itemsize); d_rgba = ctx.alloc(width * width * 4)
         cam = np.ascontiguousarray(camera); xf = np.ascontiguousarray(transform)
         _check(lib().bvh_generate_rays(ctx.handle, cam.ctypes.data, d_rays.ptr, width, width), "bvh_generate_rays")
-        _check(lib().bvh_trace_while(ctx.handle, d_rays.ptr, d_tris.ptr, d_nodes.ptr, self.result.root, n - 1, xf.ctypes.data, d_rgba.ptr, width, width), "bvh_trace_while")
+        d_cnt = ctx.alloc(width * width * 4)
+        _check(lib().bvh_trace(ctx.handle, kind, d_rays.ptr, d_tris.ptr, d_nodes.ptr, self.result.root, n - 1, xf.ctypes.data, d_rgba.ptr, d_cnt.ptr, width, width), "bvh_trace")
         out = d_rgba.download(np.uint8, width * width * 4), d_rays.download(RAY, width * width)
-        for bfr in (d_tris, d_nodes, d_rays, d_rgba):
+        if counts:
+            out = out + (d_cnt.download(np.uint32, width * width),)
+        for bfr in (d_tris, d_nodes, d_rays, d_rgba, d_cnt):
             bfr.free()
         return out
 

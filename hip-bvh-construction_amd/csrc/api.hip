@@ -489,6 +489,24 @@ int bvh_trace_while(bvh_ctx* c, const void* d_rays, const void* d_tris, const vo
     return herr(hipGetLastError());
 }
 
+// the reference's four traversal kernels behind one entry point (src/TraversalKernel.h:49-146, :148-236, :238-335, :337-451)
+int bvh_trace(bvh_ctx* c, bvh_trace_kind kind, const void* d_rays, const void* d_tris, const void* d_nodes_lbvh, uint32_t root, uint32_t n_internal,
+              const void* h_transform, void* d_rgba, uint32_t* d_ray_counter, uint32_t width, uint32_t height) {
+    if (kind == BVH_TRACE_WHILE_WHILE) {
+        int r = bvh_trace_while(c, d_rays, d_tris, d_nodes_lbvh, root, n_internal, h_transform, d_rgba, width, height);
+        if (r == 0 && d_ray_counter) { Bind b(c->device); HIP_TRY(hipMemsetAsync(d_ray_counter, 0, (size_t)width * height * 4, c->stream)); }   // (that kernel does not count)
+        return r;
+    }
+    if (!c || !d_rays || !d_tris || !d_nodes_lbvh || !h_transform || !d_rgba || !width || width != height) return BVH_E_INVALID_ARG;
+    if (kind != BVH_TRACE_RESTART_TRAIL && kind != BVH_TRACE_IF_IF && kind != BVH_TRACE_SPECULATIVE_WHILE) return BVH_E_INVALID_ARG;
+    if (kind == BVH_TRACE_RESTART_TRAIL && root != 0) return BVH_E_INVALID_ARG;       // a restart re-enters at node 0 (src/TraversalKernel.h:44)
+    Bind b(c->device);
+    HIP_TRY(hipMemcpyAsync(c->small + 32, h_transform, 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)width * height * 4, c->stream));
+    launch_trace_kind(c->stream, (int)kind, d_rays, d_tris, d_nodes_lbvh, c->small + 32, d_rgba, d_ray_counter, root, width, height, n_internal);
+    return herr(hipGetLastError());
+}
+
 int bvh_sah_cost(bvh_ctx* c, const bvh_result* in, double* cost_out) {
     if (!c || !in || !cost_out || !in->d_nodes) return BVH_E_INVALID_ARG;
     Bind b(c->device);

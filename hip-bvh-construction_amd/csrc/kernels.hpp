@@ -114,6 +114,10 @@ void launch_generate_rays(hipStream_t s, const void* d_cam, void* d_rays, uint32
 void launch_trace_while(hipStream_t s, const void* d_rays, const void* d_tris, const void* d_nodes, const void* d_xf, void* d_rgba,
                         uint32_t root, uint32_t width, uint32_t height, uint32_t n_internal);
 
+// kind: 1 restart trail, 2 if-if, 3 speculative while-while; d_counter (optional): triangle tests per ray
+void launch_trace_kind(hipStream_t s, int kind, const void* d_rays, const void* d_tris, const void* d_nodes, const void* d_xf, void* d_rgba,
+                       uint32_t* d_counter, uint32_t root, uint32_t width, uint32_t height, uint32_t n_internal);
+
 // ---- helpers (misc.hip)
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out);
 void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t root, uint32_t n, int layout, double* d_out /*[1], zeroed inside*/);

@@ -161,6 +161,13 @@ int  bvh_generate_rays(bvh_ctx* ctx, const void* h_camera, void* d_rays, uint32_
  * Square images only (the reference indexes rays with height and pixels with width). */
 int  bvh_trace_while(bvh_ctx* ctx, const void* d_rays, const void* d_tris, const void* d_nodes_lbvh, uint32_t root, uint32_t n_internal,
                      const void* h_transform, void* d_rgba, uint32_t width, uint32_t height);
+/* The reference's four traversal kernels behind one entry point: BvhTraversalRestartTrail (src/TraversalKernel.h:49-146; stackless, a
+ * restart re-enters at node 0, so root must be 0), BvhTraversalifif (:148-236), BvhTraversalWhile (:238-335), BvhTraversalSpeculativeWhile
+ * (:337-451; the wave vote spans 64 lanes here).  Same arguments as bvh_trace_while; d_ray_counter (optional, u32[width*height]) receives
+ * the triangle tests per ray (the reference's rayCounter; not counted by the while-while kernel: zeroed).  All four produce the same image. */
+typedef enum { BVH_TRACE_WHILE_WHILE = 0, BVH_TRACE_RESTART_TRAIL = 1, BVH_TRACE_IF_IF = 2, BVH_TRACE_SPECULATIVE_WHILE = 3 } bvh_trace_kind;
+int  bvh_trace(bvh_ctx* ctx, bvh_trace_kind kind, const void* d_rays, const void* d_tris, const void* d_nodes_lbvh, uint32_t root, uint32_t n_internal,
+               const void* h_transform, void* d_rgba, uint32_t* d_ray_counter, uint32_t width, uint32_t height);
 /* BVH2 SAH cost with the formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349), device reduction, f64. */
 int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
 /* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL.  h_sorted_keys: u32[n] or, for

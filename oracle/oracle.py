@@ -304,6 +304,7 @@ def ref_driver(nofma: bool = False):
     L.refdrv_hploc.argtypes = [vp, u32, vp, vp, vp, vp, C.POINTER(u32), C.c_int]
     L.refdrv_generate_rays.argtypes = [vp, vp, u32, u32]
     L.refdrv_trace_while.argtypes = [vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32]
+    L.refdrv_trace_kind.argtypes = [C.c_int, vp, vp, u32, vp, u32, vp, vp, vp, u32, u32, u32, u32]
     rc = L.refdrv_init(os.path.join(_HERE, "_ref").encode(), int(nofma))
     if rc != 0:
         raise RuntimeError("refdrv_init: " + L.refdrv_error().decode())
@@ -357,6 +358,16 @@ def ref_generate_rays(camera, width, height, nofma=False):
     rays = np.zeros(width * height, dtype=RAY)
     _rc(L, L.refdrv_generate_rays(np.ascontiguousarray(camera).ctypes.data, rays.ctypes.data, width, height), "refdrv_generate_rays")
     return rays
+
+
+def ref_trace_kind(kind, rays, tris, nodes_lbvh, transform, root, width, n_internal, nofma=False):
+    """the reference's BvhTraversalRestartTrail (1) / BvhTraversalifif (2) / BvhTraversalSpeculativeWhile (3) -> (rgba, tests per ray)"""
+    L = ref_driver(nofma); _reinit(L, nofma)
+    rgba = np.zeros(width * width * 4, dtype=np.uint8); cnt = np.zeros(width * width, dtype=np.uint32)
+    nodes_lbvh = np.ascontiguousarray(nodes_lbvh)
+    _rc(L, L.refdrv_trace_kind(kind, np.ascontiguousarray(rays).ctypes.data, tris.ctypes.data, tris.shape[0], nodes_lbvh.ctypes.data, nodes_lbvh.shape[0],
+                               np.ascontiguousarray(transform).ctypes.data, rgba.ctypes.data, cnt.ctypes.data, root, width, width, n_internal), "refdrv_trace_kind")
+    return rgba, cnt
 
 
 def ref_trace_while(rays, tris, nodes_lbvh, transform, root, width, n_internal, nofma=False):

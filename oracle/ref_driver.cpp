@@ -154,4 +154,23 @@ int refdrv_trace_while(const void* h_rays, const void* h_tris, u32 n_tris, const
     return 0;
 }
 
+// the other three traversal kernels (src/TraversalKernel.h:49-146 restart trail, :148-236 if-if, :337-451 speculative while-while);
+// kind as in bvh_trace_kind; h_counter (u32 per ray) is the reference's rayCounter (kinds 1 and 2 only)
+int refdrv_trace_kind(int kind, const void* h_rays, const void* h_tris, u32 n_tris, const void* h_nodes, u32 n_nodes, const void* h_transform,
+                      unsigned char* h_rgba, u32* h_counter, u32 root, u32 width, u32 height, u32 n_internal) {
+    Dev<B32> rays, nodes; Dev<B64> tris, xf; Dev<unsigned char> rgba; Dev<u32> cnt;
+    TRY(rays.alloc((size_t)width * height)); TRY(rays.up(h_rays)); TRY(tris.alloc(n_tris)); TRY(tris.up(h_tris));
+    TRY(nodes.alloc(n_nodes)); TRY(nodes.up(h_nodes)); TRY(xf.alloc(1)); TRY(xf.up(h_transform)); TRY(rgba.alloc((size_t)width * height * 4, 0));
+    TRY(cnt.alloc((size_t)width * height, 0));
+    const char* name = kind == 1 ? "BvhTraversalRestartTrail" : kind == 2 ? "BvhTraversalifif" : "BvhTraversalSpeculativeWhile";
+    hipFunction_t fn; RT(hipModuleGetFunction(&fn, g_trav.m, name));
+    void* with_counter[] = { &rays.p, &cnt.p, &tris.p, &nodes.p, &xf.p, &rgba.p, &root, &width, &height, &n_internal };
+    void* without[] = { &rays.p, &tris.p, &nodes.p, &xf.p, &rgba.p, &root, &width, &height, &n_internal };
+    RT(hipModuleLaunchKernel(fn, (width + 7) / 8, (height + 7) / 8, 1, 8, 8, 1, 0, nullptr, kind == 3 ? without : with_counter, nullptr));
+    RT(hipDeviceSynchronize());
+    TRY(rgba.down(h_rgba));
+    if (h_counter) TRY(cnt.down(h_counter));
+    return 0;
+}
+
 } // extern "C"

@@ -65,3 +65,33 @@ def test_image_vs_reference_kernels(pkg, orc, ctx, views, scene):
     img_default = orc.ref_trace_while(rays, tris, nodes, xf, 0, W, n - 1, nofma=False)
     diff = rgba.astype(np.int16) - img_default.astype(np.int16)
     assert np.count_nonzero(diff) <= rgba.size // 1000 and np.abs(diff).max() <= 1 or np.count_nonzero(diff) == 0
+
+
+@pytest.mark.parametrize("scene", ["cornell382", "sponza_40k", "uniform_20k"])
+@pytest.mark.parametrize("algo", [2, 3])
+def test_other_traversal_flavours(pkg, orc, ctx, views, scene, algo):
+    """restart trail / if-if / speculative while-while (bvh_trace): pixel-exact and triangle-test-count-exact against the reference's own
+    kernels on the same tree and rays (contraction off).  if-if visits in the while-while order, so it also renders the while-while
+    image everywhere; the restart trail enters the LEFT box first when both are entered at the same distance (while-while: the right
+    one) and the speculative kernel prunes with a hit distance that lags by one leaf, so where triangles tie exactly (the Sponza-like
+    room's coincident wall quads) they — the reference's kernels and these alike — keep a different one of the tied triangles."""
+    tris, cam, xf = views[scene]; n = len(tris)
+    b = pkg.BUILDERS[algo]().build(ctx, tris)            # PLOC layouts: root 0, which the restart trail requires
+    base, rays = b.render(tris, cam, xf, W)
+    nodes = b.to_lbvh_layout()
+    have_ref = os.path.exists(orc.REF_DRIVER)
+    for kind in (1, 2, 3):
+        img, _, cnt = b.render(tris, cam, xf, W, kind=kind, counts=True)
+        assert cnt.max() > 0 and img[3::4].sum() == base[3::4].sum(), "same coverage"
+        if kind == 2 or scene != "sponza_40k":
+            assert np.array_equal(img, base), f"kind {kind}: {np.count_nonzero(img != base)} bytes differ from the while-while image"
+        if have_ref:
+            rimg, rcnt = orc.ref_trace_kind(kind, rays, tris, nodes, xf, 0, W, n - 1, nofma=True)
+            assert np.array_equal(img, rimg), f"kind {kind}: {np.count_nonzero(img != rimg)} bytes differ vs the reference kernel"
+            if kind in (1, 2):
+                assert np.array_equal(cnt, rcnt), f"kind {kind}: triangle-test counts differ in {np.count_nonzero(cnt != rcnt)} rays"
+    # argument validation: the restart trail needs root 0
+    lbvh = pkg.SinglePassLbvh().build(ctx, tris)
+    if lbvh.result.root != 0:
+        with pytest.raises(pkg.BvhError):
+            lbvh.render(tris, cam, xf, W, kind=1)
