@@ -74,19 +74,32 @@ public:
         const u32 n = static_cast<u32>(primitives.size());
         bvh_result r{}; bvh_timings t{};
         check(bvh_build(context.handle(), ALGO, primitives.data(), n, 0, &r, &t), "build");
+        publish(context, r, t, n);
+    }
+    // beyond the reference (bvh_build_ex): device-resident input in any bvh_tri_format, 30- or 60-bit Morton codes.  With 60-bit codes
+    // d_sortedMortonCodeKeys64 is bound instead of d_sortedMortonCodeKeys.
+    void build(Context& context, const bvh_build_input& input, u32 n) {
+        bvh_result r{}; bvh_timings t{};
+        check(bvh_build_ex(context.handle(), ALGO, &input, n, &r, &t), "build_ex");
+        publish(context, r, t, n);
+    }
+private:
+    void publish(Context& context, const bvh_result& r, const bvh_timings& t, u32 n) {
         m_result = r;
         const size_t nodes = r.layout == 0 ? 2 * size_t(n) - 1 : size_t(n) - 1;
         d_bvhNodes.bind(context.handle(), r.d_nodes, nodes);
         d_leafNodes.bind(context.handle(), r.d_leaves, r.d_leaves ? n : 0);
         d_triangleAabb.bind(context.handle(), r.d_prim_aabbs, n);
         d_sceneExtents.bind(context.handle(), r.d_scene_extent, 1);
-        d_sortedMortonCodeKeys.bind(context.handle(), r.d_sorted_keys, n);
+        d_sortedMortonCodeKeys.bind(context.handle(), r.key_bits == 64 ? nullptr : r.d_sorted_keys, r.key_bits == 64 ? 0 : n);
+        d_sortedMortonCodeKeys64.bind(context.handle(), r.key_bits == 64 ? r.d_sorted_keys : nullptr, r.key_bits == 64 ? n : 0);
         d_sortedMortonCodeValues.bind(context.handle(), r.d_sorted_vals, n);
         m_rootNodeIdx = r.root; m_nInternalNodes = r.n_internal;
         m_timer.set(CalculateCentroidExtentsTime, t.ms_extents); m_timer.set(CalculateMortonCodesTime, t.ms_morton);
         m_timer.set(SortingTime, t.ms_sort); m_timer.set(BvhBuildTime, t.ms_build); m_timer.set(CollapseBvhTime, t.ms_collapse);
         double c = 0; check(bvh_sah_cost(context.handle(), &r, &c), "bvh_sah_cost"); m_cost = static_cast<float>(c);   // BVH2 SAH (the reference reports the BVH4 cost)
     }
+public:
     // the reference's traverseBvh() prints the perf block (src/TwoPassLbvh.cpp:300-310); the PLOC/HPLOC flavours do nothing else
     std::string perfReport() const {
         auto f = [&](int tok) { return std::to_string(m_timer.getTimeRecord(tok)); };
@@ -96,6 +109,7 @@ public:
     }
     DeviceView<Aabb> d_triangleAabb, d_sceneExtents;
     DeviceView<u32> d_sortedMortonCodeKeys, d_sortedMortonCodeValues;
+    DeviceView<uint64_t> d_sortedMortonCodeKeys64;
     DeviceView<Bvh2Node> d_bvhNodes;
     DeviceView<PrimRef> d_leafNodes;
     u32 m_rootNodeIdx = 0;
