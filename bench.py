@@ -40,6 +40,7 @@ KERNEL_BYTES_PER_PRIM = {
                                   # and 95.3 % of the internal nodes' 124 (keys 4 + R 2 children 64 + W 32 + spans 16 + counter 8)
     "k_lbvh_ext": 5.8,            # the other 4.7 % of the internal nodes (ranges crossing tiles)
     "k_karras": 100.0, "k_refit": 88.0,
+    "k_refit_block": 83.9, "k_refit_ext": 4.1,   # the refit's 88 by node share (95.3 % of the internal nodes are refitted inside a 512-leaf tile)
     "k_ploc_iter": 190.0,         # summed over all iterations
 }
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

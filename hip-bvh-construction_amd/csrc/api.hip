@@ -49,7 +49,7 @@ struct bvh_ctx {
     bvh_primref* leaves = nullptr;    // cap
     u64* slots = nullptr;             // cap           (u64 scratch: BVH4 collapse task queue)
     u32* parent = nullptr;            // 2*cap         (two-pass parent pointers / HPLOC parentIdx)
-    u32* flags = nullptr;             // cap           (two-pass refit flags)
+    u32* flags = nullptr;             // cap           (two-pass refit exchange words: all-INVALID, kept so by the protocol)
     HplocScratch hploc{};             //               (hploc.dep is zeroed when the arena is allocated and stays clean)
     PlocScratch ploc{};
     u32* small = nullptr;             // 64 words: [0] root, [1] hploc node counter, [8..9] f64 SAH
@@ -127,6 +127,7 @@ int ensure_capacity(bvh_ctx* c, uint32_t n) {
     c->arena = p; c->arena_bytes = total; c->cap = n;
     carve(c, p, n, &total);
     HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)n * sizeof(u64), c->stream));   // HPLOC dependency words: clean once, builds keep them clean
+    HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)n * sizeof(u32), c->stream));    // two-pass LBVH exchange words: likewise
     return 0;
 }
 
@@ -327,7 +328,8 @@ int bvh_emit_lbvh_two(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_so
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags);
+    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags, reinterpret_cast<unsigned char*>(c->slots),
+                    reinterpret_cast<u32*>(c->ploc.list0), 8 * (size_t)c->cap, c->hploc.queue_count);
     return herr(hipGetLastError());
 }
 
@@ -378,7 +380,8 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
     switch (algo) {
         case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
-        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags); break;
+        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags, reinterpret_cast<unsigned char*>(c->slots),
+                                                  reinterpret_cast<u32*>(c->ploc.list0), 8 * (size_t)c->cap, c->hploc.queue_count, true); break;
         case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);

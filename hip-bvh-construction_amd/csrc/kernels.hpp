@@ -69,8 +69,11 @@ size_t lbvh_queue_capacity(uint32_t n);
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count,
                         bool heads_cleared = false /* d_queue_count is already zero */);
+// d_flags: u32[n] exchange words, all 0xFFFFFFFF before the call and left so (self-cleaning); d_crosses: u8[n] scratch; d_queue (u32[queue_capacity],
+// queue_capacity >= lbvh_queue_capacity(n)) / d_queue_count (u32[64 * 32]): the tile scheduler's scratch for large n, nullptr = one-launch refit
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                     void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/);
+                     void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/, unsigned char* d_crosses /*u8[n]*/,
+                     uint32_t* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared = false);
 // HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.
 struct HplocScratch {
     void*     recs;          // 32-byte survivor records {id, rep, box} x n

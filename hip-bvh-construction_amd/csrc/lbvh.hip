@@ -30,6 +30,7 @@ __device__ __forceinline__ u64 slot_word(u32 node, u32 far) { return ((u64)(node
 // knows both children and the parent's full range, reads the sibling's box, and writes the parent node once (32 B).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr u32 LBQ_SUB = 64;        // sub-queues of the block kernel's hand-over (one atomic per block per launch)
+constexpr int LBVH_TILE = 512;     // leaves per tile of the block schedulers
 
 // the climb of one walker whose finished node `cur` (box `box`, already in memory) covers sorted positions [i, j)
 template <typename K>
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ s
 template <typename K>
 __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restrict__ boxes, const K* __restrict__ k,
                                                        const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
-                                                       u32* __restrict__ parent, u32 n) {
+                                                       u32* __restrict__ parent, unsigned char* __restrict__ crosses, u32 n) {
     __shared__ K s_keys[LBVH_BLOCK * 3 + 1];
     const int g0 = (int)(blockIdx.x * LBVH_BLOCK), w0 = g0 - LBVH_BLOCK;
     for (int t = threadIdx.x; t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : (K)0; }
@@ -222,21 +223,19 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
     const u32 rc = (s + 1 == last) ? s + 1 + ni : s + 1;
     nodes[idx].left = lc; nodes[idx].right = rc;
     parent[lc] = idx; parent[rc] = idx;
+    crosses[idx] = (first / (u32)LBVH_TILE) != (last / (u32)LBVH_TILE);   // the node's leaves span more than one tile of k_refit_block
 }
 
-__global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u32* __restrict__ parent, u32* flags, u32 n) {
-    const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
-    if (g >= n) return;
-    const u32 ni = n - 1;
-    u32 cur = ni + g;
-    Box box = box_load(&nodes[cur].aabb);                   // leaf box: written by k_karras (previous launch)
+// the refit walk of one finished node `cur` (its box is in memory) through the global second-arriver protocol.  The reference counts
+// arrivals (atomicAdd(flags) > 0, :224) and then re-reads the child links to find the sibling; exchanging the arriving child's index
+// instead hands the sibling to the second arriver directly.  The second arriver resets the word: the array stays all-INVALID.
+__device__ __forceinline__ void refit_climb(u32 cur, Box box, bvh2_node* nodes, const u32* __restrict__ parent, u32* flags) {
     u32 p = parent[cur];
     while (p != INV) {
         drain_stores();
-        // the reference counts arrivals (atomicAdd(flags) > 0, :224) and then re-reads the child links to find the sibling;
-        // exchanging the arriving child's index instead hands the sibling to the second arriver directly
         const u32 sib = __hip_atomic_exchange(flags + p, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sib == INV) break;
+        st_agent(flags + p, INV);
         compiler_fence();
         box = box_union(box, node_box_agent(nodes + sib));
         node_box_store_agent(nodes + p, box);
@@ -244,11 +243,78 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
     }
 }
 
+__global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u32* __restrict__ parent, u32* flags, u32 n) {
+    const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    const u32 cur = n - 1 + g;
+    refit_climb(cur, box_load(&nodes[cur].aabb), nodes, parent, flags);    // leaf box: written by k_karras (previous launch)
+}
+
+// Refit, large inputs: as k_lbvh_block — a workgroup owns a tile of T sorted leaves; every node whose leaves lie inside the tile (k_karras
+// recorded which do not) is refitted through LDS (parent pointers, exchange words and finished boxes all in LDS), the subtree roots whose
+// parent spans tiles are queued for k_refit_ext.  A Karras node's index is an end of its own leaf range, so a tile's nodes have tile indices.
+template <int T>
+__global__ __launch_bounds__(T) void k_refit_block(bvh2_node* __restrict__ nodes, const u32* __restrict__ parent, const unsigned char* __restrict__ crosses,
+                                                   u32* __restrict__ queue, u32* __restrict__ queue_count, u32 q_cap, u32 n) {
+    __shared__ u32 s_par_leaf[T], s_par_node[T];     // parents of leaf ni+g0+k / of internal node g0+k
+    __shared__ u32 s_slot[T];                        // per internal node: the first arriver's {index + 1}, 0 = nobody yet
+    __shared__ float s_lbox[6][T], s_nbox[6][T];     // boxes of the tile's leaves / of its finished internal nodes
+    __shared__ unsigned char s_cross[T];
+    __shared__ u32 s_q[T];
+    __shared__ u32 s_nq, s_qbase;
+    const int tid = threadIdx.x;
+    const u32 ni = n - 1, g0 = blockIdx.x * (u32)T, g = g0 + (u32)tid;
+    s_slot[tid] = 0u;
+    if (tid == 0) s_nq = 0u;
+    Box box = box_empty();
+    if (g < n) {
+        box = box_load(&nodes[ni + g].aabb);
+        s_lbox[0][tid] = box.lx; s_lbox[1][tid] = box.ly; s_lbox[2][tid] = box.lz; s_lbox[3][tid] = box.hx; s_lbox[4][tid] = box.hy; s_lbox[5][tid] = box.hz;
+        s_par_leaf[tid] = parent[ni + g];
+        if (g < ni) { s_par_node[tid] = parent[g]; s_cross[tid] = crosses[g]; }
+    }
+    __syncthreads();
+    if (g < n) {
+        u32 cur = ni + g, p = s_par_leaf[tid];
+        while (p != INV) {                                                // INV: cur is the root (single-tile input)
+            if (p < g0 || p >= g0 + (u32)T || s_cross[p - g0]) { s_q[atomicAdd(&s_nq, 1u)] = cur; break; }
+            const u32 ps = p - g0;
+            const u32 other = atomicExch(&s_slot[ps], cur + 1u);
+            if (other == 0u) break;                                       // first arriver retires (its box is parked in LDS already)
+            const u32 sib = other - 1u;
+            const bool sl = sib >= ni;
+            const u32 ss = sl ? sib - ni - g0 : sib - g0;
+            const Box sb = sl ? Box{ s_lbox[0][ss], s_lbox[1][ss], s_lbox[2][ss], s_lbox[3][ss], s_lbox[4][ss], s_lbox[5][ss] }
+                              : Box{ s_nbox[0][ss], s_nbox[1][ss], s_nbox[2][ss], s_nbox[3][ss], s_nbox[4][ss], s_nbox[5][ss] };
+            box = box_union(box, sb);
+            box_store(&nodes[p].aabb, box);                               // (child links were written by k_karras)
+            s_nbox[0][ps] = box.lx; s_nbox[1][ps] = box.ly; s_nbox[2][ps] = box.lz; s_nbox[3][ps] = box.hx; s_nbox[4][ps] = box.hy; s_nbox[5][ps] = box.hz;
+            cur = p; p = s_par_node[ps];
+        }
+    }
+    __syncthreads();
+    const u32 nq = s_nq;
+    if (nq) {
+        if (tid == 0) s_qbase = atomicAdd(queue_count + (blockIdx.x % LBQ_SUB) * 32u, nq);
+        __syncthreads();
+        const size_t base = (size_t)(blockIdx.x % LBQ_SUB) * (size_t)q_cap + s_qbase;
+        for (u32 k = (u32)tid; k < nq; k += (u32)T) queue[base + k] = s_q[k];
+    }
+}
+
+__global__ __launch_bounds__(LBVH_BLOCK) void k_refit_ext(bvh2_node* nodes, const u32* __restrict__ parent, u32* flags, const u32* __restrict__ queue,
+                                                          const u32* __restrict__ queue_count, u32 cap) {
+    const u32 sub = blockIdx.y, total = queue_count[sub * 32u];
+    for (u32 k = blockIdx.x * LBVH_BLOCK + threadIdx.x; k < total; k += gridDim.x * LBVH_BLOCK) {
+        const u32 cur = queue[(size_t)sub * cap + k];
+        refit_climb(cur, box_load(&nodes[cur].aabb), nodes, parent, flags);
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------
 // key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes).  d_slots: u64[n], all-zero (kept clean by the
 // protocol).  Large inputs: tile kernel + external climb; d_queue: uint4[queue_capacity], d_queue_count: u32[64 * 32 + 1].
-constexpr int LBVH_TILE = 512;
-constexpr uint32_t LBVH_BLOCK_MIN_N = 500000;      // below: one launch (k_lbvh_single)
+constexpr uint32_t LBVH_BLOCK_MIN_N = 500000;      // below: one launch (k_lbvh_single / k_refit)
 size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared) {
@@ -273,14 +339,29 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys,
       else                hipLaunchKernelGGL(k_lbvh_ext<u32>, g, dim3(LBVH_BLOCK), 0, s, (const u32*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, (const u32*)d_queue_count, cap, d_root, n); }
 }
 
+// d_flags: u32[n] exchange words, all-INVALID before the call and left all-INVALID (self-cleaning); d_crosses: u8[n] scratch;
+// d_queue: u32[queue_capacity] / d_queue_count: the tile scheduler's scratch for large n
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                     void* d_nodes, uint32_t* d_parent, uint32_t* d_flags) {
-    (void)hipMemsetAsync(d_flags, 0xFF, (size_t)n * sizeof(u32), s);
+                     void* d_nodes, uint32_t* d_parent, uint32_t* d_flags, unsigned char* d_crosses, uint32_t* d_queue, size_t queue_capacity,
+                     uint32_t* d_queue_count, bool heads_cleared) {
     const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
     { KernelScope ks(s, "k_karras");
-      if (key_bits == 64) hipLaunchKernelGGL(k_karras<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n);
-      else                hipLaunchKernelGGL(k_karras<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n); }
-    { KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n); }
+      if (key_bits == 64) hipLaunchKernelGGL(k_karras<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, d_crosses, n);
+      else                hipLaunchKernelGGL(k_karras<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, d_crosses, n); }
+    const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
+    const bool block = (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
+    if (!block || !d_queue) {
+        KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n);
+        return;
+    }
+    const u32 cap = (u32)(queue_capacity / LBQ_SUB);
+    if (!heads_cleared) (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
+    { KernelScope ks(s, "k_refit_block");
+      hipLaunchKernelGGL(k_refit_block<LBVH_TILE>, dim3((n + LBVH_TILE - 1) / LBVH_TILE), dim3(LBVH_TILE), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent,
+                         (const unsigned char*)d_crosses, d_queue, d_queue_count, cap, n); }
+    { KernelScope ks(s, "k_refit_ext");
+      hipLaunchKernelGGL(k_refit_ext, dim3(32, LBQ_SUB), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, (const u32*)d_queue,
+                         (const u32*)d_queue_count, cap); }
 }
 
 } // namespace bvh

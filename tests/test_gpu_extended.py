@@ -111,8 +111,8 @@ def test_morton64_and_sort64(pkg, orc, ctx, name):
 @pytest.mark.parametrize("algo", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", ["uniform_3001", "sponza_70k", "dups"])
 def test_build_60bit_keys(pkg, orc, ctx, name, algo, mode, monkeypatch):
-    if mode == "block" and algo not in (1, 3):
-        pytest.skip("scheduler choice only concerns HPLOC and single-pass LBVH")
+    if mode == "block" and algo == 2:
+        pytest.skip("scheduler choice only concerns HPLOC and the LBVH builders")
     monkeypatch.setenv("BVH_HPLOC_MODE", mode)
     monkeypatch.setenv("BVH_LBVH_MODE", "block" if mode == "block" else "single")
     tris = _dup_heavy(pkg) if name == "dups" else _meshes(pkg)[name]; n = len(tris)
