@@ -40,7 +40,8 @@ KERNEL_BYTES_PER_PRIM = {
                                   # and 95.3 % of the internal nodes' 124 (keys 4 + R 2 children 64 + W 32 + spans 16 + counter 8)
     "k_lbvh_ext": 5.8,            # the other 4.7 % of the internal nodes (ranges crossing tiles)
     "k_karras": 100.0, "k_refit": 88.0,
-    "k_refit_block": 83.9, "k_refit_ext": 4.1,   # the refit's 88 by node share (95.3 % of the internal nodes are refitted inside a 512-leaf tile)
+    # two-pass LBVH on the tile scheduler (same kernels, Karras numbering): its 188 by node share
+    "lbvh_two:k_lbvh_block": 183.9, "lbvh_two:k_lbvh_ext": 4.1,
     "k_ploc_iter": 190.0,         # summed over all iterations
 }
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -159,7 +160,8 @@ def main() -> None:
         name, (ms_sum, launches) = dom
         per_build_ms = ms_sum / args.steps                      # all launches of that kernel in one build
         launches_per_build = launches / args.steps
-        alg_bytes = KERNEL_BYTES_PER_PRIM.get(name, 0.0) * n * (launches_per_build if name == "k_onesweep" else 1.0)
+        per_prim = KERNEL_BYTES_PER_PRIM.get(f"{args.algo}:{name}", KERNEL_BYTES_PER_PRIM.get(name, 0.0))
+        alg_bytes = per_prim * n * (launches_per_build if name == "k_onesweep" else 1.0)
         achieved = alg_bytes / (per_build_ms * 1e-3) / 1e9 if per_build_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -328,8 +328,8 @@ int bvh_emit_lbvh_two(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_so
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags, reinterpret_cast<unsigned char*>(c->slots),
-                    reinterpret_cast<u32*>(c->ploc.list0), 8 * (size_t)c->cap, c->hploc.queue_count);
+    launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags, c->hploc.dep, c->small,
+                    c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count);
     return herr(hipGetLastError());
 }
 
@@ -380,8 +380,8 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
     switch (algo) {
         case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
-        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags, reinterpret_cast<unsigned char*>(c->slots),
-                                                  reinterpret_cast<u32*>(c->ploc.list0), 8 * (size_t)c->cap, c->hploc.queue_count, true); break;
+        case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags, c->hploc.dep, c->small,
+                                                  c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
         case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);

@@ -69,11 +69,11 @@ size_t lbvh_queue_capacity(uint32_t n);
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count,
                         bool heads_cleared = false /* d_queue_count is already zero */);
-// d_flags: u32[n] exchange words, all 0xFFFFFFFF before the call and left so (self-cleaning); d_crosses: u8[n] scratch; d_queue (u32[queue_capacity],
-// queue_capacity >= lbvh_queue_capacity(n)) / d_queue_count (u32[64 * 32]): the tile scheduler's scratch for large n, nullptr = one-launch refit
+// small inputs: k_karras + k_refit (d_parent u32[2n-1]; d_flags u32[n], all 0xFFFFFFFF before the call and left so); large inputs: the tile
+// scheduler with the two-pass numbering (d_slots / d_root / d_queue / d_queue_count as for launch_lbvh_single)
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                     void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/, unsigned char* d_crosses /*u8[n]*/,
-                     uint32_t* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared = false);
+                     void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/, uint64_t* d_slots, uint32_t* d_root,
+                     void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared = false);
 // HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.
 struct HplocScratch {
     void*     recs;          // 32-byte survivor records {id, rep, box} x n

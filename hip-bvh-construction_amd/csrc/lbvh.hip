@@ -32,26 +32,36 @@ __device__ __forceinline__ u64 slot_word(u32 node, u32 far) { return ((u64)(node
 constexpr u32 LBQ_SUB = 64;        // sub-queues of the block kernel's hand-over (one atomic per block per launch)
 constexpr int LBVH_TILE = 512;     // leaves per tile of the block schedulers
 
-// the climb of one walker whose finished node `cur` (box `box`, already in memory) covers sorted positions [i, j)
-template <typename K>
-__device__ __forceinline__ void lbvh_climb(u32 i, u32 j, u32 cur, Box box, const K* __restrict__ skeys, bvh2_node* nodes, u64* slots, u32* root_out, u32 n) {
+// Node numbering.  Single pass (Apetrei, src/SinglePassLbvhKernel.h): an internal node's index is its split position.  Two pass (Karras,
+// src/TwoPassLbvhKernel.h:196-216): node i covers a range that has i at one end — equivalently (the children of a node with split s are
+// `s` and `s+1`, :210-211) a left child's index is the LAST position of its range, a right child's the FIRST, the root is 0.  Both are the
+// same tree, so the same bottom-up walk emits either array: a finished node learns its own Karras index when it learns which side of its
+// parent it is, one step after it was merged — its record is therefore written at the start of the next step in both numberings.
+struct LbvhWalker { u32 i, j, cur, lc, rc; Box box; bool leaf; };      // finished node covers sorted positions [i, j)
+
+// the global part of a walker's climb: second-arriver hand-off on slots[parent], agent-scope (src/SinglePassLbvhKernel.h:88-126)
+template <typename K, bool KARRAS>
+__device__ __forceinline__ void lbvh_climb(LbvhWalker w, const K* __restrict__ skeys, bvh2_node* nodes, u64* slots, u32* root_out, u32 n) {
     while (true) {
-        if (i == 0 && j == n) { *root_out = cur; break; }   // :73 -> root (:116-120)
-        bool as_left;
-        if (i == 0) as_left = true;
-        else if (j == n) as_left = false;
-        else as_left = closer(skeys, j - 1, i - 1);
-        const u32 p = as_left ? j - 1 : i - 1;
+        const bool root = w.i == 0 && w.j == n;
+        bool as_left = true;                                // findParent (:64-86)
+        if (!root) { if (w.i == 0) as_left = true; else if (w.j == n) as_left = false; else as_left = closer(skeys, w.j - 1, w.i - 1); }
+        if (!w.leaf) {
+            if (KARRAS) w.cur = root ? 0u : (as_left ? w.j - 1 : w.i);
+            node_store_agent(nodes + w.cur, w.lc, w.rc, w.box);
+        }
+        if (root) { *root_out = w.cur; break; }             // :73 -> root (:116-120)
+        const u32 p = as_left ? w.j - 1 : w.i - 1;
         drain_stores();                                     // my node is in memory before anybody can learn its index
-        const u64 other = __hip_atomic_exchange(slots + p, slot_word(cur, as_left ? i : j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 other = __hip_atomic_exchange(slots + p, slot_word(w.cur, as_left ? w.i : w.j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (other == SLOT_EMPTY) break;                     // first arriver retires (atomicAdd(...) > 0 fails, :103)
         st_agent(slots + p, SLOT_EMPTY);                    // nobody touches this word again: leave it clean for the next build
         compiler_fence();
         const u32 sib = (u32)(other >> 32) - 1u, far = (u32)other;
-        box = box_union(box, node_box_agent(nodes + sib));  // merge(left.aabb, right.aabb) (:112) — min/max commute
-        node_store_agent(nodes + p, as_left ? cur : sib, as_left ? sib : cur, box);
-        if (as_left) j = far; else i = far;
-        cur = p;
+        w.box = box_union(w.box, node_box_agent(nodes + sib));   // merge(left.aabb, right.aabb) (:112) — min/max commute
+        w.lc = as_left ? w.cur : sib; w.rc = as_left ? sib : w.cur; w.leaf = false;
+        if (as_left) w.j = far; else w.i = far;
+        w.cur = p;                                          // (Apetrei numbering; Karras: decided next step)
     }
 }
 
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
     const u32 prim = svals[g];
     Box box = box_load(boxes + prim);                       // = bounds of Triangle[prim] (:44), computed once in stage E
     node_store_agent(nodes + ni + g, prim, INV, box);       // leaf record {left = primIdx, right = INVALID} (:36-45)
-    lbvh_climb(g, g + 1, ni + g, box, skeys, nodes, slots, root_out, n);
+    lbvh_climb<K, false>(LbvhWalker{ g, g + 1, ni + g, 0u, 0u, box, true }, skeys, nodes, slots, root_out, n);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -76,14 +86,13 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
 // whose parent leaves the tile (the ancestors of the T-aligned gaps: ~4 % of the nodes) are queued; k_lbvh_ext continues their
 // climb with the global protocol above.  Node index = split position, as before: the array is byte-identical.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename K, int T>
+template <typename K, int T, bool KARRAS>
 __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                   const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
                                                   uint4* __restrict__ queue, u32* __restrict__ queue_count, u32 q_cap, u32* root_out, u32 n) {
     __shared__ K s_key[T + 2];                       // sorted keys of positions g0-1 .. g0+T
     __shared__ u64 s_slot[T];                        // per gap: hand-off word of the first arriver (slot_word), 0 = nobody yet
-    __shared__ float s_lbox[6][T];                   // boxes of the tile's leaves
-    __shared__ float s_nbox[6][T];                   // boxes of the tile's finished internal nodes (written once, by their creator)
+    __shared__ float s_box[2][6][T];                 // per gap: the box its left / right child parked before the hand-off
     __shared__ unsigned char s_ext[T];               // per gap: the node's range leaves the tile
     __shared__ u64 s_q[T];                           // subtree roots handed to k_lbvh_ext: {node : 32 | i - g0 : 16 | j - g0 : 16}
     __shared__ u32 s_nq, s_qbase;
@@ -99,7 +108,6 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
         const u32 prim = svals[g];
         box = box_load(boxes + prim);                                     // = bounds of Triangle[prim] (:44), computed once in stage E
         node_store_plain(nodes + ni + g, prim, INV, box);                 // leaf record (:36-45); read again only by later launches
-        s_lbox[0][tid] = box.lx; s_lbox[1][tid] = box.ly; s_lbox[2][tid] = box.lz; s_lbox[3][tid] = box.hx; s_lbox[4][tid] = box.hy; s_lbox[5][tid] = box.hz;
     }
     __syncthreads();
     auto wkey = [&](u32 j) -> K { return s_key[j - g0 + 1u]; };            // j in [g0-1, g0+T]
@@ -114,32 +122,37 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
     }
     __syncthreads();
     if (g < n) {
-        u32 i = g, j = g + 1u, cur = ni + g;                              // finished node `cur` covers sorted positions [i, j)
+        u32 i = g, j = g + 1u, cur = ni + g, lc = 0u, rc = 0u;            // finished node `cur` covers sorted positions [i, j)
+        bool leaf = true;
         while (true) {
-            if (i == 0u && j == n) { *root_out = cur; break; }            // (single-tile input)
-            bool as_left;                                                 // findParent (:64-86); plen comparison == closer()
-            if (i == 0u) as_left = true;
-            else if (j == n) as_left = false;
-            else as_left = plen(wkey(j - 1u), j - 1u, wkey(j), j) > plen(wkey(i - 1u), i - 1u, wkey(i), i);
+            const bool root = i == 0u && j == n;                          // (single-tile input)
+            bool as_left = true;                                          // findParent (:64-86); plen comparison == closer()
+            if (!root) {
+                if (i == 0u) as_left = true;
+                else if (j == n) as_left = false;
+                else as_left = plen(wkey(j - 1u), j - 1u, wkey(j), j) > plen(wkey(i - 1u), i - 1u, wkey(i), i);
+            }
+            if (!leaf) {                                                  // my own record, now that (in Karras numbering) my index is known
+                if (KARRAS) cur = root ? 0u : (as_left ? j - 1u : i);
+                node_store_plain(nodes + cur, lc, rc, box);
+            }
+            if (root) { *root_out = cur; break; }
             const u32 p = as_left ? j - 1u : i - 1u;
             if (p < g0 || s_ext[p - g0]) {                                // parent leaves the tile: hand the subtree root over
                 s_q[atomicAdd(&s_nq, 1u)] = ((u64)cur << 32) | ((u64)(i - g0) << 16) | (u64)(j - g0);
                 break;
             }
             const u32 ps = p - g0;
+            const int side = as_left ? 0 : 1;                             // park my box, then publish (LDS operations of a wave execute in order)
+            s_box[side][0][ps] = box.lx; s_box[side][1][ps] = box.ly; s_box[side][2][ps] = box.lz; s_box[side][3][ps] = box.hx; s_box[side][4][ps] = box.hy; s_box[side][5][ps] = box.hz;
             const u64 other = atomicExch(reinterpret_cast<unsigned long long*>(&s_slot[ps]), (unsigned long long)slot_word(cur, as_left ? i : j));
-            if (other == SLOT_EMPTY) break;                               // first arriver retires (its box is parked in LDS already)
+            if (other == SLOT_EMPTY) break;                               // first arriver retires
             const u32 sib = (u32)(other >> 32) - 1u, far = (u32)other;
-            const bool sl = sib >= ni;                                    // sibling is a leaf / an internal node of this tile
-            const u32 ss = sl ? sib - ni - g0 : sib - g0;
-            const Box sb = sl ? Box{ s_lbox[0][ss], s_lbox[1][ss], s_lbox[2][ss], s_lbox[3][ss], s_lbox[4][ss], s_lbox[5][ss] }
-                              : Box{ s_nbox[0][ss], s_nbox[1][ss], s_nbox[2][ss], s_nbox[3][ss], s_nbox[4][ss], s_nbox[5][ss] };
+            const Box sb = { s_box[1 - side][0][ps], s_box[1 - side][1][ps], s_box[1 - side][2][ps], s_box[1 - side][3][ps], s_box[1 - side][4][ps], s_box[1 - side][5][ps] };
             box = box_union(box, sb);                                     // merge(left.aabb, right.aabb) (:112) — min/max commute
-            node_store_plain(nodes + p, as_left ? cur : sib, as_left ? sib : cur, box);
-            // park the new node's box before its own hand-off (LDS operations of a wave execute in order)
-            s_nbox[0][ps] = box.lx; s_nbox[1][ps] = box.ly; s_nbox[2][ps] = box.lz; s_nbox[3][ps] = box.hx; s_nbox[4][ps] = box.hy; s_nbox[5][ps] = box.hz;
+            lc = as_left ? cur : sib; rc = as_left ? sib : cur; leaf = false;
             if (as_left) j = far; else i = far;
-            cur = p;
+            cur = p;                                                      // (Apetrei numbering; Karras: decided next step)
         }
     }
     __syncthreads();
@@ -155,8 +168,8 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
     }
 }
 
-// the subtree roots queued by k_lbvh_block continue with the global second-arriver protocol
-template <typename K>
+// the subtree roots queued by k_lbvh_block (records written, boxes in memory) continue with the global second-arriver protocol
+template <typename K, bool KARRAS>
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ skeys, bvh2_node* nodes, u64* slots, const uint4* __restrict__ queue,
                                                          const u32* __restrict__ queue_count, u32 cap, u32* root_out, u32 n) {
     const u32 sub = blockIdx.y;
@@ -164,7 +177,8 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ s
     for (u32 k = blockIdx.x * LBVH_BLOCK + threadIdx.x; k < total; k += gridDim.x * LBVH_BLOCK) {
         const uint4 it = queue[(size_t)sub * cap + k];
         const Box box = box_load(&nodes[it.x].aabb);                      // written by k_lbvh_block (previous launch)
-        lbvh_climb(it.y, it.z, it.x, box, skeys, nodes, slots, root_out, n);
+        // (handed over as "leaf": its record exists already, only its parent's side is still to be found)
+        lbvh_climb<K, KARRAS>(LbvhWalker{ it.y, it.z, it.x, 0u, 0u, box, true }, skeys, nodes, slots, root_out, n);
     }
 }
 
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ s
 template <typename K>
 __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restrict__ boxes, const K* __restrict__ k,
                                                        const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
-                                                       u32* __restrict__ parent, unsigned char* __restrict__ crosses, u32 n) {
+                                                       u32* __restrict__ parent, u32 n) {
     __shared__ K s_keys[LBVH_BLOCK * 3 + 1];
     const int g0 = (int)(blockIdx.x * LBVH_BLOCK), w0 = g0 - LBVH_BLOCK;
     for (int t = threadIdx.x; t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : (K)0; }
@@ -223,7 +237,6 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
     const u32 rc = (s + 1 == last) ? s + 1 + ni : s + 1;
     nodes[idx].left = lc; nodes[idx].right = rc;
     parent[lc] = idx; parent[rc] = idx;
-    crosses[idx] = (first / (u32)LBVH_TILE) != (last / (u32)LBVH_TILE);   // the node's leaves span more than one tile of k_refit_block
 }
 
 // the refit walk of one finished node `cur` (its box is in memory) through the global second-arriver protocol.  The reference counts
@@ -250,118 +263,58 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
     refit_climb(cur, box_load(&nodes[cur].aabb), nodes, parent, flags);    // leaf box: written by k_karras (previous launch)
 }
 
-// Refit, large inputs: as k_lbvh_block — a workgroup owns a tile of T sorted leaves; every node whose leaves lie inside the tile (k_karras
-// recorded which do not) is refitted through LDS (parent pointers, exchange words and finished boxes all in LDS), the subtree roots whose
-// parent spans tiles are queued for k_refit_ext.  A Karras node's index is an end of its own leaf range, so a tile's nodes have tile indices.
-template <int T>
-__global__ __launch_bounds__(T) void k_refit_block(bvh2_node* __restrict__ nodes, const u32* __restrict__ parent, const unsigned char* __restrict__ crosses,
-                                                   u32* __restrict__ queue, u32* __restrict__ queue_count, u32 q_cap, u32 n) {
-    __shared__ u32 s_par_leaf[T], s_par_node[T];     // parents of leaf ni+g0+k / of internal node g0+k
-    __shared__ u32 s_slot[T];                        // per internal node: the first arriver's {index + 1}, 0 = nobody yet
-    __shared__ float s_lbox[6][T], s_nbox[6][T];     // boxes of the tile's leaves / of its finished internal nodes
-    __shared__ unsigned char s_cross[T];
-    __shared__ u32 s_q[T];
-    __shared__ u32 s_nq, s_qbase;
-    const int tid = threadIdx.x;
-    const u32 ni = n - 1, g0 = blockIdx.x * (u32)T, g = g0 + (u32)tid;
-    s_slot[tid] = 0u;
-    if (tid == 0) s_nq = 0u;
-    Box box = box_empty();
-    if (g < n) {
-        box = box_load(&nodes[ni + g].aabb);
-        s_lbox[0][tid] = box.lx; s_lbox[1][tid] = box.ly; s_lbox[2][tid] = box.lz; s_lbox[3][tid] = box.hx; s_lbox[4][tid] = box.hy; s_lbox[5][tid] = box.hz;
-        s_par_leaf[tid] = parent[ni + g];
-        if (g < ni) { s_par_node[tid] = parent[g]; s_cross[tid] = crosses[g]; }
-    }
-    __syncthreads();
-    if (g < n) {
-        u32 cur = ni + g, p = s_par_leaf[tid];
-        while (p != INV) {                                                // INV: cur is the root (single-tile input)
-            if (p < g0 || p >= g0 + (u32)T || s_cross[p - g0]) { s_q[atomicAdd(&s_nq, 1u)] = cur; break; }
-            const u32 ps = p - g0;
-            const u32 other = atomicExch(&s_slot[ps], cur + 1u);
-            if (other == 0u) break;                                       // first arriver retires (its box is parked in LDS already)
-            const u32 sib = other - 1u;
-            const bool sl = sib >= ni;
-            const u32 ss = sl ? sib - ni - g0 : sib - g0;
-            const Box sb = sl ? Box{ s_lbox[0][ss], s_lbox[1][ss], s_lbox[2][ss], s_lbox[3][ss], s_lbox[4][ss], s_lbox[5][ss] }
-                              : Box{ s_nbox[0][ss], s_nbox[1][ss], s_nbox[2][ss], s_nbox[3][ss], s_nbox[4][ss], s_nbox[5][ss] };
-            box = box_union(box, sb);
-            box_store(&nodes[p].aabb, box);                               // (child links were written by k_karras)
-            s_nbox[0][ps] = box.lx; s_nbox[1][ps] = box.ly; s_nbox[2][ps] = box.lz; s_nbox[3][ps] = box.hx; s_nbox[4][ps] = box.hy; s_nbox[5][ps] = box.hz;
-            cur = p; p = s_par_node[ps];
-        }
-    }
-    __syncthreads();
-    const u32 nq = s_nq;
-    if (nq) {
-        if (tid == 0) s_qbase = atomicAdd(queue_count + (blockIdx.x % LBQ_SUB) * 32u, nq);
-        __syncthreads();
-        const size_t base = (size_t)(blockIdx.x % LBQ_SUB) * (size_t)q_cap + s_qbase;
-        for (u32 k = (u32)tid; k < nq; k += (u32)T) queue[base + k] = s_q[k];
-    }
-}
-
-__global__ __launch_bounds__(LBVH_BLOCK) void k_refit_ext(bvh2_node* nodes, const u32* __restrict__ parent, u32* flags, const u32* __restrict__ queue,
-                                                          const u32* __restrict__ queue_count, u32 cap) {
-    const u32 sub = blockIdx.y, total = queue_count[sub * 32u];
-    for (u32 k = blockIdx.x * LBVH_BLOCK + threadIdx.x; k < total; k += gridDim.x * LBVH_BLOCK) {
-        const u32 cur = queue[(size_t)sub * cap + k];
-        refit_climb(cur, box_load(&nodes[cur].aabb), nodes, parent, flags);
-    }
-}
-
 // ---- launchers ---------------------------------------------------------------------------------------------------
 // key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes).  d_slots: u64[n], all-zero (kept clean by the
 // protocol).  Large inputs: tile kernel + external climb; d_queue: uint4[queue_capacity], d_queue_count: u32[64 * 32 + 1].
 constexpr uint32_t LBVH_BLOCK_MIN_N = 500000;      // below: one launch (k_lbvh_single / k_refit)
 size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
+static bool lbvh_use_tiles(uint32_t n) {
+    const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
+    return (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
+}
+// tile kernel + external climb; karras: emit the two-pass builder's node numbering instead of the single-pass one
+static void launch_lbvh_tiles(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n, void* d_nodes,
+                              uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared, bool karras) {
+    const u32 cap = (u32)(queue_capacity / LBQ_SUB);    // per sub-queue
+    if (!heads_cleared) (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
+    const dim3 gt((n + LBVH_TILE - 1) / LBVH_TILE), bt(LBVH_TILE), ge(32, LBQ_SUB), be(LBVH_BLOCK);
+#define LB_TILES(KK, KAR) do { \
+        { KernelScope ks(s, "k_lbvh_block"); hipLaunchKernelGGL((k_lbvh_block<KK, LBVH_TILE, KAR>), gt, bt, 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
+                                                                (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n); } \
+        { KernelScope ks(s, "k_lbvh_ext"); hipLaunchKernelGGL((k_lbvh_ext<KK, KAR>), ge, be, 0, s, (const KK*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, \
+                                                              (const u32*)d_queue_count, cap, d_root, n); } } while (0)
+    if (key_bits == 64) { if (karras) LB_TILES(u64, true); else LB_TILES(u64, false); }
+    else                { if (karras) LB_TILES(u32, true); else LB_TILES(u32, false); }
+#undef LB_TILES
+}
+
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared) {
-    const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
-    const bool block = (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
-    if (!block || !d_queue) {
+    if (!lbvh_use_tiles(n) || !d_queue) {
         const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
         KernelScope ks(s, "k_lbvh_single");
         if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_single<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
         else                hipLaunchKernelGGL(k_lbvh_single<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
         return;
     }
-    const u32 cap = (u32)(queue_capacity / LBQ_SUB);    // per sub-queue
-    if (!heads_cleared) (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
-    const u32 tiles = (n + LBVH_TILE - 1) / LBVH_TILE;
-    { KernelScope ks(s, "k_lbvh_block");
-      if (key_bits == 64) hipLaunchKernelGGL((k_lbvh_block<u64, LBVH_TILE>), dim3(tiles), dim3(LBVH_TILE), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n);
-      else                hipLaunchKernelGGL((k_lbvh_block<u32, LBVH_TILE>), dim3(tiles), dim3(LBVH_TILE), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n); }
-    { KernelScope ks(s, "k_lbvh_ext");
-      const dim3 g(32, LBQ_SUB);
-      if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_ext<u64>, g, dim3(LBVH_BLOCK), 0, s, (const u64*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, (const u32*)d_queue_count, cap, d_root, n);
-      else                hipLaunchKernelGGL(k_lbvh_ext<u32>, g, dim3(LBVH_BLOCK), 0, s, (const u32*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, (const u32*)d_queue_count, cap, d_root, n); }
+    launch_lbvh_tiles(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_slots, d_root, d_queue, queue_capacity, d_queue_count, heads_cleared, false);
 }
 
-// d_flags: u32[n] exchange words, all-INVALID before the call and left all-INVALID (self-cleaning); d_crosses: u8[n] scratch;
-// d_queue: u32[queue_capacity] / d_queue_count: the tile scheduler's scratch for large n
+// Two pass.  Small inputs: k_karras + k_refit (d_parent: u32[2n-1]; d_flags: u32[n] exchange words, all-INVALID before the call and left so).
+// Large inputs: the same tree is the single-pass tree with another numbering, so the tile scheduler emits it directly (no range
+// searches, no parent array): d_slots / d_root / d_queue / d_queue_count as for launch_lbvh_single.
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                     void* d_nodes, uint32_t* d_parent, uint32_t* d_flags, unsigned char* d_crosses, uint32_t* d_queue, size_t queue_capacity,
+                     void* d_nodes, uint32_t* d_parent, uint32_t* d_flags, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity,
                      uint32_t* d_queue_count, bool heads_cleared) {
-    const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
-    { KernelScope ks(s, "k_karras");
-      if (key_bits == 64) hipLaunchKernelGGL(k_karras<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, d_crosses, n);
-      else                hipLaunchKernelGGL(k_karras<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, d_crosses, n); }
-    const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
-    const bool block = (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
-    if (!block || !d_queue) {
-        KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n);
+    if (lbvh_use_tiles(n) && d_queue) {
+        launch_lbvh_tiles(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_slots, d_root, d_queue, queue_capacity, d_queue_count, heads_cleared, true);
         return;
     }
-    const u32 cap = (u32)(queue_capacity / LBQ_SUB);
-    if (!heads_cleared) (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
-    { KernelScope ks(s, "k_refit_block");
-      hipLaunchKernelGGL(k_refit_block<LBVH_TILE>, dim3((n + LBVH_TILE - 1) / LBVH_TILE), dim3(LBVH_TILE), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent,
-                         (const unsigned char*)d_crosses, d_queue, d_queue_count, cap, n); }
-    { KernelScope ks(s, "k_refit_ext");
-      hipLaunchKernelGGL(k_refit_ext, dim3(32, LBQ_SUB), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, (const u32*)d_queue,
-                         (const u32*)d_queue_count, cap); }
+    const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
+    { KernelScope ks(s, "k_karras");
+      if (key_bits == 64) hipLaunchKernelGGL(k_karras<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n);
+      else                hipLaunchKernelGGL(k_karras<u32>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_parent, n); }
+    { KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n); }
 }
 
 } // namespace bvh
