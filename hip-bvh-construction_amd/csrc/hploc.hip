@@ -533,8 +533,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 
 // External nodes (ranges crossing the tiles of k_hploc_block): the sub-queues hold the nodes whose dependencies were complete
 // when the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
+#ifndef HPX_OCC
+#define HPX_OCC 6        // waves per SIMD of k_hploc_ext (80 VGPRs; measured 0.97 ms emit at 10 M vs 0.98 unconstrained, 1.00 at 7, 1.13 at 8)
+#endif
 template <typename K>
-__global__ __launch_bounds__(256) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
+__global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                    const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes,
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, const u32* __restrict__ q_count, u32 q_cap, u32 n) {
