@@ -275,7 +275,7 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__
         const int p = (int)pc;
         const K kp = key_at(p);
         const int c0 = plen(kp, (u32)p, key_at(p + 1), (u32)p + 1u);             // common prefix length of the node
-        auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && plen(key_at(j), (u32)j, kp, (u32)p) >= c0; };
+        auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && shares_prefix(key_at(j), (u32)j, kp, (u32)p, c0); };
         {   // leftmost leaf sharing the prefix (n < 2^30: int arithmetic cannot overflow)
             int step = 1;
             while (inside(p - step)) step <<= 1;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const int p = (int)pc;
             const K kp = wkey(p);
             const int c0 = plen(kp, (u32)p, wkey(p + 1), (u32)p + 1u);
-            auto inside = [&](int j) -> bool { return plen(wkey(j), (u32)j, kp, (u32)p) >= c0; };
+            auto inside = [&](int j) -> bool { return shares_prefix(wkey(j), (u32)j, kp, (u32)p, c0); };
             // the positions sharing the node's prefix are contiguous around p: plain binary searches over the window for the two
             // ends (a fixed ~log2(T) probes per side; an exponential search costs the wave its longest lane: ~2x as many)
             int lo = p, hi = p + 1;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 const int p = (int)pc;
                 const K kp = gkey(p);
                 const int c0 = plen(kp, (u32)p, gkey(p + 1), (u32)p + 1u);
-                auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && plen(gkey(j), (u32)j, kp, (u32)p) >= c0; };
+                auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && shares_prefix(gkey(j), (u32)j, kp, (u32)p, c0); };
                 const bool lbig = inside(p - (int)HP_HALF), rbig = inside(p + 1 + (int)HP_HALF);
                 int lo = p, hi = p + 1;
                 if (!lbig) { for (int t = 8; t > 0; t >>= 1) if (inside(lo - t)) lo -= t; }          // L in [p-15, p]
