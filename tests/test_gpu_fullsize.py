@@ -92,3 +92,24 @@ def test_sponza_262k_all_builders_vs_oracle(pkg, orc, ctx):
     # PLOC variants must not be worse than LBVH on their own metric (config 4: "SAH <= reference")
     sah = {a: pkg.BUILDERS[a]().build(ctx, tris).sah_cost() for a in (1, 2, 3)}
     assert sah[2] < sah[1] and sah[3] < sah[1]
+
+
+@pytest.mark.parametrize("n,kind", [(1_234_567, "sponza"), (600_001, "bunny")])
+def test_tile_schedulers_at_odd_sizes(pkg, orc, ctx, n, kind):
+    """sizes that are no multiple of anything, above the tile schedulers' thresholds: LBVH arrays byte-exact, HPLOC topology, PLOC++ valid"""
+    tris = pkg.meshgen.sponza_like(n, 3) if kind == "sponza" else pkg.meshgen.bunny_like(n, 2)
+    n = len(tris)
+    fe = orc.front_end(tris)
+    for algo in (0, 1, 3, 2):
+        got = pkg.BUILDERS[algo]().build(ctx, tris).download()
+        assert np.array_equal(got["sorted_keys"], fe["skeys"]) and np.array_equal(got["sorted_vals"], fe["svals"])
+        assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
+        if algo == 1:
+            ref, root = orc.lbvh_single(tris, fe["skeys"], fe["svals"])
+            assert root == got["root"] and got["nodes"].tobytes() == ref.tobytes()
+        elif algo == 0:
+            ref, _ = orc.lbvh_two(tris, fe["skeys"], fe["svals"])
+            assert got["nodes"].tobytes() == ref.tobytes()
+        elif algo == 3:
+            hn, hl, _ = orc.hploc(fe["boxes"], fe["skeys"], fe["svals"])
+            assert got["leaves"].tobytes() == hl.tobytes() and orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(hn, hl, 0, n, 1)
