@@ -8,7 +8,7 @@
 // Design (CDNA4):
 //  * 8-bit digits; every pass reads each pair once and writes it once (16 B per pair per pass) — the digit histograms of
 //    ALL passes are produced up front (fused into the Morton kernel, or by k_hist for the stand-alone entry point), so no
-//    pass re-reads keys to count.
+//    pass re-reads keys to count; every tile scans the 256 raw counts of its pass itself (no scan launch).
 //  * one workgroup (4 wave64) sorts a tile of 4096 pairs: per-wave ranking by ballot "match-any" (8 ballots per key, no
 //    LDS atomics, stable by construction), per-wave digit counters in LDS, a cross-wave scan, then the tile's digit totals
 //    are chained to earlier tiles by decoupled look-back on 32-bit status words {flag:2, count:30}.  Status words are
@@ -61,22 +61,6 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
     for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&hist[i], c); }
 }
 
-// per-pass exclusive scan of the digit counts, in place.  grid = passes, block = SORT_RADIX
-__global__ __launch_bounds__(SORT_RADIX) void k_scan_hist(u32* __restrict__ hist) {
-    __shared__ u32 s[SORT_RADIX];
-    u32* h = hist + blockIdx.x * SORT_RADIX;
-    const u32 v = h[threadIdx.x];
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < SORT_RADIX; off <<= 1) {
-        const u32 t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s[threadIdx.x] += t;
-        __syncthreads();
-    }
-    h[threadIdx.x] = s[threadIdx.x] - v;
-}
-
 // IN_AOS / OUT_AOS: the pair arrays of the intermediate passes are interleaved {key, value} u64 words — a tile's run for one
 // digit is then 16 x 8 B = a full 128-byte line instead of two 64-byte half lines (measured: scattered SoA writes cost 36 % of a
 // pass).  The caller-facing arrays of the first and last pass stay SoA (KeyValueSoA of Oro::RadixSort::sort).
@@ -92,7 +76,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     using Rec = PairRec<K>;
     __shared__ K s_keys[SORT_TILE];
     __shared__ u32 s_vals[SORT_TILE];
-    __shared__ u32 s_wsum[NW];
+    __shared__ u64 s_wsum[NW];
     __shared__ u32 s_tile;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -153,17 +137,21 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
         if ((u32)tid == digit_mask) total -= (u32)SORT_TILE - valid;     // padding keys (all ones) carry the top digit; they are not data
         st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | total);
     }
-    // ---- exclusive scan of the 256 digit totals (wave scan + LDS hop) -> s_binoff
+    // ---- exclusive scans over the 256 digits (wave scan + LDS hop), two in one: the tile's digit totals -> s_binoff, and the pass's
+    // raw global digit counts -> gexcl (every tile redoes that 256-entry scan from L2: cheaper than a kernel launch per sort)
+    u32 gexcl;
     {
-        u32 inc = total;
+        const u32 graw = ghist[tid];
+        u64 inc = ((u64)graw << 32) | total;
 #pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) { const u32 t = (u32)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
+        for (int off = 1; off < WAVE; off <<= 1) { const u64 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
         if (lane == WAVE - 1) s_wsum[wave] = inc;
         __syncthreads();
-        u32 wbase = 0;
+        u64 wbase = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) if (w < wave) wbase += s_wsum[w];
-        s_binoff[tid] = wbase + inc - total;
+        const u64 ex = wbase + inc - (((u64)graw << 32) | total);
+        s_binoff[tid] = (u32)ex; gexcl = (u32)(ex >> 32);
     }
     // ---- decoupled look-back for digit `tid`: LB_WINDOW predecessors are fetched per step (independent loads in flight)
     // so that a walk over k tiles costs ~k/LB_WINDOW memory round trips instead of k
@@ -192,7 +180,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
             }
             st_agent(&status[(size_t)tile * SORT_RADIX + tid], ST_INCL | (excl + total));
         }
-        s_gbase[tid] = ghist[tid] + excl - s_binoff[tid];
+        s_gbase[tid] = gexcl + excl - s_binoff[tid];
     }
     __syncthreads();
 
@@ -261,7 +249,6 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         KernelScope ks(s, "k_hist");
         hipLaunchKernelGGL(k_hist<K>, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
-    { KernelScope ks(s, "k_scan_hist"); hipLaunchKernelGGL(k_scan_hist, dim3(passes), dim3(SORT_RADIX), 0, s, sc.hist); }
 #ifdef BVH_ABLATION
     const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // measurements only: results are wrong when set
 #else
