@@ -31,7 +31,6 @@ KERNEL_BYTES_PER_PRIM = {
     "k_extents": 88.0,            # R Triangle 64 + W Aabb 24
     "k_morton": 32.0,             # R Aabb 24 + W key 4 + W val 4   (this build: 28, value is implicit)
     "k_onesweep": 17.0,           # per pass: R 8 + W 8 (+ hist R 4 amortised over 4 passes)
-    "k_ploc_setup": 88.0,         # SetupClusters for PLOC++: R val 4 + gather Aabb 24 + W PrimRef 28 + W list entry 32
     "k_hploc": 198.0,             # one-launch HPLOC (n < 1 M): SetupClusters 64 + HPloc 134 (keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32)
     "k_hploc_block": 177.9,       # block-local kernel: SetupClusters 64 + 85 % of HPloc's 134 (the merge tasks whose range lies inside a 512-leaf tile)
     "k_hploc_ext": 20.1,          # the other 15 % of the merge tasks (ranges crossing tiles)
@@ -42,7 +41,7 @@ KERNEL_BYTES_PER_PRIM = {
     "k_karras": 100.0, "k_refit": 88.0,
     # two-pass LBVH on the tile scheduler (same kernels, Karras numbering): its 188 by node share
     "lbvh_two:k_lbvh_block": 183.9, "lbvh_two:k_lbvh_ext": 4.1,
-    "k_ploc_iter": 190.0,         # summed over all iterations
+    "k_ploc_iter": 250.0,         # summed over all iterations: SetupClusters 60 (fused into the first iteration) + the iterations' 190
 }
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 

@@ -146,9 +146,10 @@ struct Bind { int prev = -1; bool ok = true;
 
 // PLOC++ iteration driver: batches of device-side iterations, one small read-back per batch (src/PLOC++Bvh.cpp:132-152
 // reads back after EVERY iteration).
-int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, const void* d_leaves, const PlocScratch& sc, uint32_t* iterations_out) {
+int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const u32* d_svals, const PlocScratch& sc, uint32_t* iterations_out) {
     u32 host_state[PLOC_STATE_WORDS];
     int first = 0, parity = 0;
+    bool fresh = true;
     // iterations needed grow by ~3 per doubling of n (measured: 30 at 262 k, 45 at 10 M); the first batch aims slightly above
     int batch = 33; for (uint32_t m = n; m > 262144u; m >>= 1) batch += 3; if (batch > 80) batch = 80; if (n < 262144u) batch = 33;
     for (int guard = 0; guard < 4096; ++guard) {
@@ -161,7 +162,8 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, const void* d_leaves, const 
             ploc_reset(c->stream, sc, n, count);
             first = 0;
         }
-        ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, first, batch, parity);
+        ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh);
+        fresh = false;
         HIP_TRY(hipMemcpyAsync(host_state, sc.state, sizeof host_state, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const u32 count = host_state[first + batch];
@@ -338,9 +340,9 @@ int bvh_emit_ploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted
     if (!c || !d_prim_aabbs || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    ploc_begin(c->stream, c->ploc, d_prim_aabbs, d_sorted_vals, n, d_leaves);
+    ploc_begin(c->stream, c->ploc, n);
     HIP_TRY(hipGetLastError());
-    return run_ploc(c, n, d_nodes, d_leaves, c->ploc, iterations_out);
+    return run_ploc(c, n, d_nodes, d_leaves, d_prim_aabbs, d_sorted_vals, c->ploc, iterations_out);
 }
 
 int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted_keys, const uint32_t* d_sorted_vals, uint32_t n,
@@ -384,8 +386,8 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
                                                   c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
         case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
-        case BVH_PLOCPP:          ploc_begin(s, c->ploc, c->boxes, c->svals, n, c->leaves);
-                                  r = run_ploc(c, n, c->nodes, c->leaves, c->ploc, &ploc_iters); if (r) return r;
+        case BVH_PLOCPP:          ploc_begin(s, c->ploc, n);
+                                  r = run_ploc(c, n, c->nodes, c->leaves, c->boxes, c->svals, c->ploc, &ploc_iters); if (r) return r;
                                   out->d_leaves = c->leaves; out->layout = 1; break;
     }
     HIP_TRY(hipGetLastError());

@@ -101,9 +101,11 @@ constexpr int PLOC_CHUNK = 1024;
 constexpr int PLOC_MAX_ITERS = 96;
 constexpr int PLOC_STATE_WORDS = 2 * PLOC_MAX_ITERS + 4;     // counts[MAX+1] | tickets[MAX] | iterations done
 inline uint32_t ploc_chunks(uint32_t n) { return (n + PLOC_CHUNK - 1) / PLOC_CHUNK; }
-void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves);
+void ploc_begin(hipStream_t s, const PlocScratch& sc, uint32_t n);
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count);
-void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity);
+// fresh: iteration `first` is the build's very first one — it reads d_svals / d_boxes and writes d_leaves (SetupClusters fused)
+void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals,
+                  int first, int count, int parity, bool fresh);
 
 // ---- BVH2 -> BVH4 collapse (collapse.hip)
 constexpr int COLLAPSE_MAX_LEVELS = 192;

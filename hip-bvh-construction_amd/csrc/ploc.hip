@@ -16,6 +16,9 @@
 
 namespace bvh {
 
+#ifndef PLOC_NARROW
+#define PLOC_NARROW 512
+#endif
 #ifndef PLOC_ABL
 #define PLOC_ABL 0       // measurements only (tools/build_variant.sh): 1 no look-back wait, 2 no NN search, 3 no list stores — results are wrong
 #endif
@@ -54,19 +57,6 @@ __device__ __forceinline__ void entry_store(float4* __restrict__ list, size_t g,
     list[2 * g + 1] = make_float4(b.hx, b.hy, b.hz, 0.0f);
 }
 
-// SetupClusters (:39-55): leaf records + the initial cluster list
-__global__ __launch_bounds__(256) void k_ploc_setup(const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals,
-                                                    bvh_primref* __restrict__ leaves, float4* __restrict__ list, u32 n) {
-    const u32 g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n) return;
-    const u32 prim = svals[g];
-    const Box b = box_load(boxes + prim);
-    float* f = reinterpret_cast<float*>(leaves + g);
-    reinterpret_cast<u32*>(f)[0] = prim;
-    f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-    entry_store(list, g, g + (n - 1), b);
-}
-
 // nearest neighbour of span entry k among valid entries [lo, hi) within +-8, key {area bits, position}
 __device__ __forceinline__ u32 nearest(const PlocLds& s, int k, int lo, int hi) {
     const Box b = lds_box(s, k);
@@ -98,20 +88,35 @@ __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
 }
 
 // counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
-template <int PL_BLOCK>
+// FIRST: the build's first iteration reads the clusters straight from the sorted values and the primitive boxes and writes the
+// PrimRef leaves on the way — SetupClusters (:39-55) fused: the initial cluster list (32 B written + 32 B read per primitive) never exists.
+template <int PL_BLOCK, bool FIRST>
 __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
                                                         bvh2_node* __restrict__ nodes,
-                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni) {
+                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
+                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
     constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
     __shared__ PlocLds s;
     const u32 C = counts[0];
     if (C <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = C; return; }
     const int tid = threadIdx.x;
+    // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
+    auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
+        if (FIRST) {
+            const u32 prim = svals[g];
+            b = box_load(boxes + prim); id = (u32)g + ni;
+            if (own) {
+                float* f = reinterpret_cast<float*>(leaves + g);
+                reinterpret_cast<u32*>(f)[0] = prim;
+                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+            }
+        } else entry_load(list_in, g, id, b);
+    };
 
     if (C < (u32)PLOC_CHUNK) {
         // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
         if (blockIdx.x != 0) return;
-        for (int k = tid; k < (int)C; k += PL_BLOCK) { u32 id; Box b; entry_load(list_in, (size_t)k, id, b); lds_set(s, k, id, b); }
+        for (int k = tid; k < (int)C; k += PL_BLOCK) { u32 id; Box b; fetch((size_t)k, true, id, b); lds_set(s, k, id, b); }
         __syncthreads();
         u32 c = C;
         while (c > 1) {
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
         // span entry k <-> list position o - HALO + k   (:232-249)
         for (int k = tid; k < PL_SPAN; k += PL_BLOCK) {
             const long long gpos = o - PL_HALO + k;
-            if (gpos >= 0 && gpos < (long long)C) { u32 id; Box b; entry_load(list_in, (size_t)gpos, id, b); lds_set(s, k, id, b); }
+            if (gpos >= 0 && gpos < (long long)C) { u32 id; Box b; fetch((size_t)gpos, k >= PL_HALO && k < PL_HALO + PLOC_CHUNK, id, b); lds_set(s, k, id, b); }
             else s.id[k] = INV;
         }
         __syncthreads();
@@ -246,10 +251,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
 __global__ void k_ploc_init(u32* state, u32 n) { if (threadIdx.x == 0) state[0] = n; }
 
 // state words: counts[0..MAX_ITERS] | tickets[0..MAX_ITERS) | iterations done
-void ploc_begin(hipStream_t s, const PlocScratch& sc, const void* d_boxes, const uint32_t* d_svals, uint32_t n, void* d_leaves) {
-    { KernelScope ks(s, "k_ploc_setup"); hipLaunchKernelGGL(k_ploc_setup, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves, (float4*)sc.list0, n); }
-    ploc_reset(s, sc, n, n);
-}
+void ploc_begin(hipStream_t s, const PlocScratch& sc, uint32_t n) { ploc_reset(s, sc, n, n); }
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count) {
     hipMemsetAsync(sc.state, 0, PLOC_STATE_WORDS * sizeof(u32), s);
     hipMemsetAsync(sc.status, 0, (size_t)PLOC_MAX_ITERS * ploc_chunks(n) * sizeof(u64), s);
@@ -258,8 +260,9 @@ void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count
 // enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads.  The host does not
 // know the cluster count of an iteration; it only shapes the launch from a guess (C shrinks by ~20 % per iteration): any grid
 // is correct because chunks are taken from a ticket counter, a good guess is merely faster.
-void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, const void* d_leaves, int first, int count, int parity) {
-    (void)d_leaves;
+// fresh: iteration `first` is the build's very first one (reads svals / boxes, writes the leaves: fused SetupClusters)
+void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals,
+                  int first, int count, int parity, bool fresh) {
     const u32 chunks = ploc_chunks(n);
     u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
     KernelScope ks(s, "k_ploc_iter");                   // the batch of launches is timed as one group
@@ -269,11 +272,12 @@ void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_node
         const bool wide = guess <= 1024.0;                                              // a few workgroups per CU at most: latency matters
         u32 grid = (u32)(2.0 * guess) + 8u; if (grid > (wide ? 512u : 1024u)) grid = wide ? 512u : 1024u; if (grid > chunks) grid = chunks;
         const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);
-#ifndef PLOC_NARROW
-#define PLOC_NARROW 512
-#endif
-        if (wide) hipLaunchKernelGGL(k_ploc_iter<1024>, dim3(grid), dim3(1024), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
-        else      hipLaunchKernelGGL(k_ploc_iter<PLOC_NARROW>,  dim3(grid), dim3(PLOC_NARROW),  0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, counts + k, tickets + k, done, n - 1);
+        const bool f0 = fresh && k == first;
+#define PLOC_LAUNCH(BLK, FIRST) hipLaunchKernelGGL((k_ploc_iter<BLK, FIRST>), dim3(grid), dim3(BLK), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, \
+                                                   counts + k, tickets + k, done, n - 1, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves)
+        if (wide) { if (f0) PLOC_LAUNCH(1024, true); else PLOC_LAUNCH(1024, false); }
+        else      { if (f0) PLOC_LAUNCH(PLOC_NARROW, true); else PLOC_LAUNCH(PLOC_NARROW, false); }
+#undef PLOC_LAUNCH
     }
 }
 
