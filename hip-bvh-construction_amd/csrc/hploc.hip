@@ -128,8 +128,12 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
 // PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
 // registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
 // read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
+#ifndef HP_NN_LDS
+#define HP_NN_LDS 1
+#endif
+// nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (HP_NN_LDS)
 template <bool AGENT = true>
-__device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase) {
+__device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, u64* nn) {
         const bool have = w.have, final_ = w.final_;
         u32 id = w.id, rep = w.rep, cnt = w.cnt;
         Box b = w.b;
@@ -139,11 +143,19 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
             // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
             // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
+#if HP_NN_LDS
+            // findNearestNeighbours (:83-117) as the reference does it: every pair's area is evaluated once and minimised, as the 64-bit key
+            // {area bits, neighbour slot}, into BOTH ends' words — LDS atomics (ds_min_u64; a wave's LDS operations execute in order, so the
+            // reset below, the atomics and the read-back need no barrier).  The selection costs no VALU work beyond the validity test.
+            nn[lane] = ~0ull;
+            u64 bestR = ~0ull; (void)bestR;
+#else
+            // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
+            // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
+            // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
             u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
-            // neighbour fetches: ds_bpermute with the lane distance in the instruction's immediate offset (byte address
-            // lane*4 + 4r, wraps modulo the wave) — no address arithmetic; radii up to HP_DPP_R come from a DPP shift chain
-            // instead (VALU moves), the rest from the LDS crossbar: the split balances the two pipes
             const int la = lane << 2;
+#endif
             Box nb = b;
             // two candidates per step so that the area arithmetic runs as packed f32 (v_pk_add/mul_f32: two lanes of a register pair
             // per instruction); the min/max of the unions have no packed form.  Same operations, same association, no contraction.
@@ -162,13 +174,34 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
                 for (int q = 0; q < 2; ++q) {
                     const int rr = r + q;
                     const u32 ab = __float_as_uint(q ? area.y : area.x);
+#if HP_NN_LDS == 1
+                    if (act && (u32)(slot + rr) < cnt) {                         // both ends are clusters of this task
+                        atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
+                        atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
+                    }
+#elif HP_NN_LDS == 2
+                    if (act && (u32)(slot + rr) < cnt) {                         // the far end learns about me through LDS, my own side stays in registers
+                        atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
+                        const u64 key = ((u64)ab << 32) | (u32)(slot + rr);
+                        bestR = key < bestR ? key : bestR;
+                    }
+#else
                     const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * rr), (int)ab);   // area(slot - rr, slot)
                     if ((u32)(slot + rr) < cnt && ab < abR) { abR = ab; idR = slot + rr; }
                     if (slot >= rr && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - rr; }
+#endif
                 }
             }
             // mergeClusters (:126-190)
+#if HP_NN_LDS == 1
+            const int nbr = (int)(u32)nn[lane];
+#elif HP_NN_LDS == 2
+            asm volatile("" ::: "memory");           // (the read below must stay behind the other lanes' atomics on my word: nothing in the
+            const u64 bestL = nn[lane];              //  abstract machine orders it after this thread's atomics on OTHER words)
+            const int nbr = (int)(u32)(bestL < bestR ? bestL : bestR);
+#else
             const int nbr = (abL <= abR) ? idL : idR;
+#endif
             const int nsrc = hbase + nbr;
             const u32 nbr_of_nbr = (u32)__shfl(nbr, nsrc);
             const bool in = act && (u32)slot < cnt;
@@ -219,7 +252,7 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
 template <bool SETUP, typename K>
 __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                             const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs,
-                                            u64* dep, u32* zero_parent, u32 ni, int lane) {
+                                            u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
     while (true) {
         const u64 rm = __ballot(ready);
@@ -237,7 +270,7 @@ __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, co
         if (owner && !(L == 0u && R == ni)) q = parent_gap(L, R, ni, [&](u32 a, u32 b) { return closer(skeys, a, b); });
 
         HpWork w = load_work<SETUP>(have, tL, tR, tP, boxes, svals, leaves, recs, ni, slot, hbase);
-        ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase);
+        ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn);
         // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
         if (have && !w.final_ && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);
 
@@ -299,7 +332,8 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__
         }
     }
     if (dbg == 1) return;
-    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, ni, lane);
+    __shared__ u64 s_nn[HP_BLOCK / WAVE][WAVE];
+    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, ni, lane, s_nn[threadIdx.x / WAVE]);
 }
 
 // =====================================================================================================================
@@ -343,6 +377,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ u32 s_cnt[128], s_off[128];
     __shared__ u32 s_npub, s_nready, s_qbase;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
+    __shared__ u64 s_nn[NT / WAVE][WAVE];            // per wave: nearest-neighbour keys of the PLOC rounds
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
@@ -444,7 +479,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 w.id = decode_id(e_id[sp]); w.rep = g0 + e_rep[sp];
                 w.b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
             }
-            ploc_rounds<false>(w, nodes, zero_parent, ni, lane, slot, hbase);
+            ploc_rounds<false>(w, nodes, zero_parent, ni, lane, slot, hbase, s_nn[wave]);
             if (have && slot < 16) {                 // storeIndices (:208-218) into the range's first 16 positions
                 const u32 d = L + (u32)slot;
                 e_id[d] = (unsigned short)(w.id == INV ? 0xFFFFu : (w.id >= ni ? 0x8000u | (w.id - ni - g0) : w.id - g0));
@@ -541,6 +576,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
                                                    const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes,
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, const u32* __restrict__ q_count, u32 q_cap, u32 n) {
+    __shared__ u64 s_nn[256 / WAVE][WAVE];
     const int lane = threadIdx.x & (WAVE - 1);
     const u32 nwaves = gridDim.x * (256 / WAVE);
     const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
@@ -551,7 +587,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         const bool ready = (lane & 31) == 0 && idx < total;
         u32 pc = 0, L = 0, R = 0;
         if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
-        async_climb<false>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane);
+        async_climb<false>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE]);
     }
 }
 
@@ -564,8 +600,8 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
     else                hipLaunchKernelGGL(k_hploc<u32>, g, b, 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, n, hploc_ablation());
 }
 
-// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  Tile 512 leaves / 256 threads / 6 waves per SIMD
-// (80 VGPRs, no spills; 7 waves = 72 VGPRs spill since the rounds evaluate two candidates per step) measured best on MI355X.
+// Block-local HPLOC for large n (n > 2 tiles: the root is never local).  Tile 512 leaves / 256 threads / 7 waves per SIMD (72 VGPRs,
+// 3 spilled) measured best on MI355X with the LDS-atomic neighbour selection: 10 M emit 0.94 ms vs 0.97 at 6 waves.
 #ifndef HPB_T
 #define HPB_T 512
 #endif
@@ -573,7 +609,7 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
 #define HPB_NT 256
 #endif
 #ifndef HPB_OCC
-#define HPB_OCC 6
+#define HPB_OCC 7
 #endif
 static void hpb_config(int* t, int* nt, int* occ) {
     *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
