@@ -129,7 +129,7 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
 // registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
 // read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
 #ifndef HP_NN_LDS
-#define HP_NN_LDS 1
+#define HP_NN_LDS 1        // 1: neighbour selection by LDS atomic minima (default); 0: two running minima in registers (same speed, 246 -> 210 VALU/round)
 #endif
 // nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (HP_NN_LDS)
 template <bool AGENT = true>
@@ -148,7 +148,6 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             // {area bits, neighbour slot}, into BOTH ends' words — LDS atomics (ds_min_u64; a wave's LDS operations execute in order, so the
             // reset below, the atomics and the read-back need no barrier).  The selection costs no VALU work beyond the validity test.
             nn[lane] = ~0ull;
-            u64 bestR = ~0ull; (void)bestR;
 #else
             // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
             // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
@@ -179,12 +178,6 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
                         atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
                         atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
                     }
-#elif HP_NN_LDS == 2
-                    if (act && (u32)(slot + rr) < cnt) {                         // the far end learns about me through LDS, my own side stays in registers
-                        atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
-                        const u64 key = ((u64)ab << 32) | (u32)(slot + rr);
-                        bestR = key < bestR ? key : bestR;
-                    }
 #else
                     const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * rr), (int)ab);   // area(slot - rr, slot)
                     if ((u32)(slot + rr) < cnt && ab < abR) { abR = ab; idR = slot + rr; }
@@ -195,10 +188,6 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             // mergeClusters (:126-190)
 #if HP_NN_LDS == 1
             const int nbr = (int)(u32)nn[lane];
-#elif HP_NN_LDS == 2
-            asm volatile("" ::: "memory");           // (the read below must stay behind the other lanes' atomics on my word: nothing in the
-            const u64 bestL = nn[lane];              //  abstract machine orders it after this thread's atomics on OTHER words)
-            const int nbr = (int)(u32)(bestL < bestR ? bestL : bestR);
 #else
             const int nbr = (abL <= abR) ? idL : idR;
 #endif
