@@ -238,14 +238,13 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
 
 // ---- the asynchronous part: run ready merge tasks, two per pass (one per 32-lane half of the wave), then hand the finished
 // range to the parent node (dep_arrive); a lane that completes its parent runs it next.  No waiting anywhere.
+// one pass: the first two ready lanes' tasks run (rm = ballot(ready), non-zero); their owners move on to the parent if they complete it
 template <bool SETUP, typename K>
-__device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
-                                            const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs,
-                                            u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn) {
+__device__ __forceinline__ void climb_pass(u64 rm, bool& ready, u32& pc, u32& L, u32& R, const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
+                                           const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs,
+                                           u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
-    while (true) {
-        const u64 rm = __ballot(ready);
-        if (!rm) break;
+    {
         const int ownA = __ffsll((unsigned long long)rm) - 1;
         const u64 rm2 = rm & (rm - 1);
         const int ownB = rm2 ? __ffsll((unsigned long long)rm2) - 1 : -1;
@@ -271,6 +270,16 @@ __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, co
                 pc = q;
             }
         }
+    }
+}
+template <bool SETUP, typename K>
+__device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
+                                            const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs,
+                                            u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn) {
+    while (true) {
+        const u64 rm = __ballot(ready);
+        if (!rm) break;
+        climb_pass<SETUP>(rm, ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, ni, lane, nn);
     }
 }
 
@@ -560,17 +569,43 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #ifndef HPX_OCC
 #define HPX_OCC 6        // waves per SIMD of k_hploc_ext (80 VGPRs; measured 0.97 ms emit at 10 M vs 0.98 unconstrained, 1.00 at 7, 1.13 at 8)
 #endif
-template <typename K>
+// TICKETS (inputs >= HPX_TICKETS_MIN_N): a task owner (lanes 0 and 32) that is not climbing takes the next item of its sub-queue
+// through a ticket word next to the count, so a wave that keeps climbing with one task fills its other half from the queue
+// instead of running half empty.  Two-stage pipeline so that the wave never waits for it: ticket requested in one pass, item
+// loaded in the next, run in the third.  Small inputs are a pure dependency chain where the static deal is faster (same box,
+// k_hploc_ext us, static / tickets: 1 M 90 / 108, 2 M 102 / 116, 10 M 249 / 242, 40 M 934 / 743).
+constexpr u32 HPX_TICKETS_MIN_N = 8000000u;
+template <typename K, bool TICKETS>
 __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                    const u32* __restrict__ svals, bvh_primref* leaves, bvh2_node* nodes,
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
-                                                   const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, const u32* __restrict__ q_count, u32 q_cap, u32 n) {
+                                                   const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, u32* q_count, u32 q_cap, u32 n) {
     __shared__ u64 s_nn[256 / WAVE][WAVE];
     const int lane = threadIdx.x & (WAVE - 1);
     const u32 nwaves = gridDim.x * (256 / WAVE);
     const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-    const u32 sub = wid % HPQ_SUB, wsub = wid / HPQ_SUB, nwsub = nwaves / HPQ_SUB;       // (nwaves is a multiple of HPQ_SUB)
+    const u32 sub = wid % HPQ_SUB;                                       // (nwaves is a multiple of HPQ_SUB)
     const u32 total = q_count[sub * 32u];
+    if (TICKETS) {
+        u32* head = q_count + sub * 32u + 1u;
+        constexpr u32 NO_TICKET = 0xFFFFFFFFu;
+        bool ready = false, dry = false, have_item = false;
+        u32 pc = 0, L = 0, R = 0, tk = NO_TICKET, ipc = 0; u64 irg = 0;
+        while (true) {
+            if (have_item && !ready) { pc = ipc; L = (u32)irg; R = (u32)(irg >> 32); ready = true; have_item = false; }
+            if (tk != NO_TICKET && !have_item) {
+                if (tk < total) { const size_t at = (size_t)sub * q_cap + tk; ipc = q_pc[at]; irg = q_rng[at]; have_item = true; }
+                else dry = true;
+                tk = NO_TICKET;
+            }
+            if ((lane & 31) == 0 && !ready && !have_item && tk == NO_TICKET && !dry) tk = atomicAdd(head, 1u);
+            const u64 rm = __ballot(ready);
+            if (!rm) { if (__ballot(tk != NO_TICKET || have_item)) continue; break; }
+            climb_pass<false>(rm, ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE]);
+        }
+        return;
+    }
+    const u32 wsub = wid / HPQ_SUB, nwsub = nwaves / HPQ_SUB;
     for (u32 base = wsub * 2u; base < total; base += nwsub * 2u) {       // wave-uniform
         const u32 idx = base + (u32)(lane >> 5);
         const bool ready = (lane & 31) == 0 && idx < total;
@@ -628,10 +663,12 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
     KernelScope ks(s, "k_hploc_ext");
     const u32 xg = 2048u;                               // 8 waves per SIMD (measured flat from 2048 to 8192 workgroups); a multiple of 16:
                                                         // waves are dealt to the 64 sub-queues round-robin
-    if (key_bits == 64) hipLaunchKernelGGL(k_hploc_ext<u64>, dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
-                       (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
-    else                hipLaunchKernelGGL(k_hploc_ext<u32>, dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const u32*)d_skeys, d_svals, (bvh_primref*)d_leaves, (bvh2_node*)d_nodes,
-                       (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, (const u32*)sc.queue_count, q_cap, n);
+#define HPX_LAUNCH(KK, TT) hipLaunchKernelGGL((k_hploc_ext<KK, TT>), dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, (bvh_primref*)d_leaves, \
+                       (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, sc.queue_count, q_cap, n)
+    const bool tickets = n >= HPX_TICKETS_MIN_N;
+    if (key_bits == 64) { if (tickets) HPX_LAUNCH(u64, true); else HPX_LAUNCH(u64, false); }
+    else                { if (tickets) HPX_LAUNCH(u32, true); else HPX_LAUNCH(u32, false); }
+#undef HPX_LAUNCH
 }
 
 } // namespace bvh

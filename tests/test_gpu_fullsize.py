@@ -49,6 +49,24 @@ def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
     assert hashes[0] == hashes[1], "block-local and asynchronous HPLOC schedulers must build the same tree"
 
 
+def test_hploc_ticket_climb_on_clustered_60bit_keys(pkg, orc, ctx):
+    """above 8 M leaves k_hploc_ext deals its queue by tickets; a clustered mesh with u64 keys, both schedulers, same tree"""
+    tris = pkg.meshgen.sponza_like(8_000_123, 5); n = len(tris)
+    d_tris = ctx.upload(tris)
+    hashes = []
+    for mode in ("block", "async"):
+        os.environ["BVH_HPLOC_MODE"] = mode
+        try:
+            got = pkg.HPLOC().build_ex(ctx, n, tris=d_tris, morton_bits=60).download()
+        finally:
+            del os.environ["BVH_HPLOC_MODE"]
+        k = got["sorted_keys"]
+        assert k.dtype == np.uint64 and np.all(k[1:] >= k[:-1])
+        assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
+        hashes.append(orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1))
+    assert hashes[0] == hashes[1]
+
+
 @pytest.mark.parametrize("algo", [1, 0])
 def test_lbvh_10m_bit_exact(pkg, orc, ctx, big, algo):
     """the LBVH oracle is linear-time: bit-exact comparison at full size"""
