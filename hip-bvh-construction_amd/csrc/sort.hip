@@ -64,6 +64,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 // IN_AOS / OUT_AOS: the pair arrays of the intermediate passes are interleaved {key, value} u64 words — a tile's run for one
 // digit is then 16 x 8 B = a full 128-byte line instead of two 64-byte half lines (measured: scattered SoA writes cost 36 % of a
 // pass).  The caller-facing arrays of the first and last pass stay SoA (KeyValueSoA of Oro::RadixSort::sort).
+#ifndef SORT_EXCHANGE_FIRST
+#define SORT_EXCHANGE_FIRST 1
+#endif
 template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS>
 __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
@@ -80,6 +83,13 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     __shared__ u32 s_tile;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+#ifdef BVH_ABLATION
+    u64 ts[8]; int nts = 0;
+#define SORT_STAMP() do { if (dbg & 16) ts[nts] = __builtin_amdgcn_s_memtime(); ++nts; } while (0)
+#else
+#define SORT_STAMP() do { } while (0)
+#endif
+    SORT_STAMP();                                    // 0: start
     if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
 #pragma unroll
     for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
@@ -102,6 +112,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
             val[i] = IOTA ? (base + local) : (ok ? vals_in[base + local] : 0u);
         }
     }
+#ifdef BVH_ABLATION
+    if (dbg & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SORT_STAMP();                                    // 1: ticket + loads landed
     // ---- rank inside the wave: lanes holding the same digit form a group (8 ballots); every member reads the wave's LDS
     // counter for that digit, the group's lowest lane bumps it; rank = counter-before + index inside the group.  Program order
     // (item-major, then lane) is exactly memory order inside the wave's span => stable.
@@ -126,6 +140,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
         pos[i] = before + below;
     }
     __syncthreads();
+    SORT_STAMP();                                    // 2: ranked
 
     // ---- digit `tid`: totals over the 4 waves, exclusive wave offsets back into s_whist, publish the tile aggregate
     u32 total;
@@ -153,14 +168,32 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
         const u64 ex = wbase + inc - (((u64)graw << 32) | total);
         s_binoff[tid] = (u32)ex; gexcl = (u32)(ex >> 32);
     }
+#if SORT_EXCHANGE_FIRST
+    // ---- tile-local sort through LDS, ahead of the look-back: it needs nothing from other tiles, and the predecessors publish meanwhile
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; ++i) {
+        const u32 d = (u32)(key[i] >> shift) & digit_mask;
+        const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
+        s_keys[p] = key[i]; s_vals[p] = val[i];
+    }
+#endif
+    SORT_STAMP();                                    // 3: totals published, scans, exchange writes
     // ---- decoupled look-back for digit `tid`: LB_WINDOW predecessors are fetched per step (independent loads in flight)
-    // so that a walk over k tiles costs ~k/LB_WINDOW memory round trips instead of k
+    // so that a walk over k tiles costs ~k/LB_WINDOW memory round trips instead of k.  Measured at 10 M (BVH_SORT_DEBUG=16 in the
+    // ablation build): 9.4 steps per tile, 2.8 of them empty polls; skipping the look-back altogether takes a pass from 70 to
+    // 45 us, but neither wider windows (16: 74 us, 32: 83 us), nor 8-tile skip words (5.5 steps: 68 us), nor more workgroups per CU,
+    // nor dedicated scanner waves (tiles polling one word: 230+ us, the scanners' round trips serialise) recover any of it: what
+    // costs is that every tile keeps its CU slot until its slowest predecessor has published.
     {
         u32 excl = 0;
         if (tile > 0 && !(dbg & 1)) {
             constexpr int LB_WINDOW = 8;
             int prev = (int)tile - 1;
             bool done = false;
+#ifdef BVH_ABLATION
+            u32 n_steps = 0, n_empty = 0;
+#endif
             while (!done) {
                 u32 st[LB_WINDOW];
 #pragma unroll
@@ -176,14 +209,23 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
                     if (flag == 2) done = true;
                 }
                 prev -= used;
+#ifdef BVH_ABLATION
+                ++n_steps; if (used == 0) ++n_empty;
+#endif
                 if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef BVH_ABLATION
+            if ((dbg & 16) && tid == 0) { atomicAdd(tile_counter + 4, n_steps); atomicAdd(tile_counter + 8, n_empty); atomicMax(tile_counter + 12, n_steps); }
+#endif
             st_agent(&status[(size_t)tile * SORT_RADIX + tid], ST_INCL | (excl + total));
         }
         s_gbase[tid] = gexcl + excl - s_binoff[tid];
     }
+    SORT_STAMP();                                    // 4: own look-back done
     __syncthreads();
+    SORT_STAMP();                                    // 5: everybody's look-back done
 
+#if !SORT_EXCHANGE_FIRST
     // ---- tile-local sort through LDS
 #pragma unroll
     for (int i = 0; i < SORT_IPT; ++i) {
@@ -192,6 +234,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
         s_keys[p] = key[i]; s_vals[p] = val[i];
     }
     __syncthreads();
+#endif
 #pragma unroll
     for (int k = 0; k < SORT_IPT; ++k) {
         const u32 p = (u32)(k * SORT_BLOCK + tid);
@@ -202,8 +245,24 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
             else { keys_out[dst] = kk; vals_out[dst] = s_vals[p]; }
         }
     }
+#ifdef BVH_ABLATION
+    if (dbg & 16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SORT_STAMP();                                // 6: scattered
+        if (tid == 0) for (int k = 1; k < 7; ++k) atomicAdd(tile_counter + 16 + k, (u32)(ts[k] - ts[k - 1]));
+    }
+#endif
+#undef SORT_STAMP
 }
 
+#ifdef BVH_ABLATION
+__global__ void k_lb_report(u32* c, u32 tiles, int pass) {
+    printf("pass %d: %u tiles, look-back steps/tile %.2f (max %u), empty polls/tile %.2f\n", pass, tiles, (double)c[4] / tiles, c[12], (double)c[8] / tiles);
+    printf("   thread 0's clock ticks per tile: load %.0f  rank %.0f  totals+scan+exchange %.0f  look-back %.0f  wait for the block %.0f  scatter %.0f\n",
+           (double)c[17] / tiles, (double)c[18] / tiles, (double)c[19] / tiles, (double)c[20] / tiles, (double)c[21] / tiles, (double)c[22] / tiles);
+    for (int k = 16; k < 24; ++k) c[k] = 0u;
+}
+#endif
 __global__ void k_iota(u32* __restrict__ out, u32 n) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = i;
@@ -220,7 +279,11 @@ __global__ __launch_bounds__(256) void k_prepare(u32* __restrict__ hist, u32 his
     for (u32 i = t; i < status_vecs; i += stride) status[i] = make_uint4(0u, 0u, 0u, 0u);
     for (u32 i = t; i < hist_words; i += stride) hist[i] = 0u;
     for (u32 i = t; i < extra_words; i += stride) extra[i] = 0u;
+#ifdef BVH_ABLATION
+    if (t < 64u) counters[t] = 0u;                   // (+ the look-back statistics of the measurement build; the array is padded to 256 bytes)
+#else
     if (t < (u32)SORT_MAX_PASSES) counters[t] = 0u;
+#endif
     if (scene && t < 6u) scene[t] = t < 3u ? FMAX : -FMAX;
 }
 
@@ -274,6 +337,9 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         else if (last)          SWEEP(false, true, false);
         else                    SWEEP(false, true, true);
 #undef SWEEP
+#ifdef BVH_ABLATION
+        if (dbg & 16) hipLaunchKernelGGL(k_lb_report, dim3(1), dim3(1), 0, s, tc, tiles, p);
+#endif
         kin = kout; vin = vout;
     }
 }

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""stage S alone (bvh_sort_pairs on random 30-bit keys, 10 M) for kernel traces of the BVH_SORT_DEBUG ablations"""
+import os, sys
+import numpy as np
+import torch
+torch.cuda.init()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bvh_pkg
+pkg = bvh_pkg.load(); ctx = pkg.Context(0); L = pkg.lib()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+keys = np.random.default_rng(1).integers(0, 1 << 30, n, dtype=np.uint32)
+d_k = ctx.upload(keys); d_sk = ctx.alloc(n * 4); d_sv = ctx.alloc(n * 4)
+for _ in range(10): assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_sk.ptr, d_sv.ptr, 0, 30) == 0
+ctx.synchronize()
