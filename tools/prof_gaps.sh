@@ -8,7 +8,7 @@ python - "$f" <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-starts = [i for i, r in enumerate(rows) if "k_reset_scene" in r[0]]
+starts = [i for i, r in enumerate(rows) if "k_prepare" in r[0]]
 a = starts[-2]; b = starts[-1]          # the last complete timed build
 t0 = rows[a][1]; busy = 0
 for n, s, e in rows[a:b]:
