@@ -9,8 +9,8 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 it = [(s, e) for n, s, e in rows if "k_ploc_iter" in n]
-# last build = last group of launches; split builds by k_ploc_setup
-setups = [s for n, s, e in rows if "k_ploc_setup" in n]
+# last build = last group of launches; split builds by k_ploc_init
+setups = [s for n, s, e in rows if "k_ploc_init" in n]
 last = setups[-1]
 it = [(s, e) for s, e in it if s > last]
 print("launches in last build:", len(it))
