@@ -39,7 +39,9 @@ constexpr int SORT_BLOCK = 256;
 #define BVH_SORT_IPT 16
 #endif
 constexpr int SORT_IPT = BVH_SORT_IPT;                        // keys per thread
-constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup
+constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup (sizes the status rows)
+constexpr int SORT_IPT_WIDE = 20;                            // keys per thread for large inputs
+constexpr uint32_t SORT_WIDE_MIN_N = 1000000;
 constexpr int SORT_MAX_PASSES = 8;                          // 8 digits: 64-bit keys
 struct SortScratch {
     void*     pairs0;        // interleaved {key,value} records of the intermediate passes, ping (8 B x n for u32 keys, 16 B x n for u64)

@@ -67,18 +67,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 #ifndef SORT_EXCHANGE_FIRST
 #define SORT_EXCHANGE_FIRST 1
 #endif
-template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS>
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT>
 __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
                                                          int shift, u32 digit_mask, const u32* __restrict__ ghist,
                                                          u32* status, u32* tile_counter, int dbg) {
     constexpr int NW = SORT_BLOCK / WAVE;
+    constexpr int TILE = SORT_BLOCK * IPT;           // keys per workgroup
     __shared__ u32 s_whist[NW][SORT_RADIX];
     __shared__ u32 s_binoff[SORT_RADIX];
     __shared__ u32 s_gbase[SORT_RADIX];
     using Rec = PairRec<K>;
-    __shared__ K s_keys[SORT_TILE];
-    __shared__ u32 s_vals[SORT_TILE];
+    __shared__ K s_keys[TILE];
+    __shared__ u32 s_vals[TILE];
     __shared__ u64 s_wsum[NW];
     __shared__ u32 s_tile;
 
@@ -95,14 +96,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
     __syncthreads();
     const u32 tile = s_tile;
-    const u32 base = tile * (u32)SORT_TILE;
-    const u32 valid = min((u32)SORT_TILE, n - base);
+    const u32 base = tile * (u32)TILE;
+    const u32 valid = min((u32)TILE, n - base);
 
     // ---- load (wave-striped: wave w owns a contiguous 64*IPT span, item i is a coalesced 256-B row of it)
-    K key[SORT_IPT]; u32 val[SORT_IPT], pos[SORT_IPT];
+    K key[IPT]; u32 val[IPT], pos[IPT];
 #pragma unroll
-    for (int i = 0; i < SORT_IPT; ++i) {
-        const u32 local = (u32)(wave * WAVE * SORT_IPT + i * WAVE + lane);
+    for (int i = 0; i < IPT; ++i) {
+        const u32 local = (u32)(wave * WAVE * IPT + i * WAVE + lane);
         const bool ok = local < valid;
         if (IN_AOS) {
             const typename Rec::type kv = ok ? reinterpret_cast<const typename Rec::type*>(keys_in)[base + local] : Rec::pad();   // (a select, not a
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     // (item-major, then lane) is exactly memory order inside the wave's span => stable.
     const u64 lt = lanemask_lt();
 #pragma unroll
-    for (int i = 0; i < SORT_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const u32 d = (u32)(key[i] >> shift) & digit_mask;
         // lanes whose digit differs from mine in bit b: ballot(bit b) xor (my bit b, sign-extended); the group is what is left
         u32 diff_lo = 0u, diff_hi = 0u;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #pragma unroll
         for (int w = 0; w < NW; ++w) { const u32 c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
         total = run;
-        if ((u32)tid == digit_mask) total -= (u32)SORT_TILE - valid;     // padding keys (all ones) carry the top digit; they are not data
+        if ((u32)tid == digit_mask) total -= (u32)TILE - valid;     // padding keys (all ones) carry the top digit; they are not data
         st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | total);
     }
     // ---- exclusive scans over the 256 digits (wave scan + LDS hop), two in one: the tile's digit totals -> s_binoff, and the pass's
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     // ---- tile-local sort through LDS, ahead of the look-back: it needs nothing from other tiles, and the predecessors publish meanwhile
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SORT_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const u32 d = (u32)(key[i] >> shift) & digit_mask;
         const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
         s_keys[p] = key[i]; s_vals[p] = val[i];
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #if !SORT_EXCHANGE_FIRST
     // ---- tile-local sort through LDS
 #pragma unroll
-    for (int i = 0; i < SORT_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const u32 d = (u32)(key[i] >> shift) & digit_mask;
         const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
         s_keys[p] = key[i]; s_vals[p] = val[i];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     __syncthreads();
 #endif
 #pragma unroll
-    for (int k = 0; k < SORT_IPT; ++k) {
+    for (int k = 0; k < IPT; ++k) {
         const u32 p = (u32)(k * SORT_BLOCK + tid);
         if (p < valid) {
             const K kk = s_keys[p];
@@ -306,7 +307,11 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         else hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, vals_out, n);
         return;
     }
-    const u32 tiles = sort_tiles(n);
+    // keys per thread: 16, from SORT_WIDE_MIN_N on 20 (same box, 4 passes: 10 M 0.299 -> 0.280 ms, 2 M 0.114 -> 0.113, 262 k 0.064 -> 0.067:
+    // fewer tiles = fewer status rows for everybody's look-back, but a longer critical path per tile)
+    const bool wide = n >= SORT_WIDE_MIN_N;
+    const u32 tile_keys = (u32)SORT_BLOCK * (wide ? SORT_IPT_WIDE : SORT_IPT);
+    const u32 tiles = (n + tile_keys - 1u) / tile_keys;           // (<= sort_tiles(n): the status rows were sized and cleared for that)
     if (!hist_ready) {
         const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
         KernelScope ks(s, "k_hist");
@@ -331,7 +336,8 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         u32* tc = sc.counters + p;
         KernelScope ks(s, "k_onesweep");
         const dim3 g(tiles), b(SORT_BLOCK);
-#define SWEEP(IOTA, INA, OUTA) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg)
+#define SWEEP(IOTA, INA, OUTA) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_IPT_WIDE>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
+                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_IPT>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
         if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }
         else if (last)          SWEEP(false, true, false);
