@@ -53,6 +53,11 @@ struct bvh_ctx {
     HplocScratch hploc{};             //               (hploc.dep is zeroed when the arena is allocated and stays clean)
     PlocScratch ploc{};
     u32* small = nullptr;             // 64 words: [0] root, [1] hploc node counter, [8..9] f64 SAH
+    size_t lbvh_queue_capacity = 0;   // uint4 entries of ploc.list0 (>= kernels.hpp lbvh_queue_capacity(cap))
+    // The emitters' self-cleaning scratch (hploc.dep / LBVH slots all-zero, two-pass flags all-ones) is only clean after a build that ran to
+    // completion.  Set while an emit is being enqueued, cleared when every launch of it was accepted: a build that failed in between
+    // (HIP error, early return) makes the next one re-initialise the words instead of silently producing wrong trees.
+    bool scratch_dirty = false;
     hipEvent_t ev[6] = {};
 };
 
@@ -106,7 +111,8 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->hploc.queue_pc = k.take<u32>(c->hploc.queue_capacity);
     c->hploc.queue_rng = k.take<u64>(c->hploc.queue_capacity);
     c->hploc.queue_count = k.take<u32>(64 * 32 + 32);      // (+ one word: sub-queue capacity for the LBVH tile scheduler)
-    c->ploc.list0 = k.take<uint4>(2 * n);
+    c->lbvh_queue_capacity = 2 * n > lbvh_queue_capacity(cap) ? 2 * n : lbvh_queue_capacity(cap);   // list0 doubles as the LBVH tile scheduler's root queue
+    c->ploc.list0 = k.take<uint4>(c->lbvh_queue_capacity);
     c->ploc.list1 = k.take<uint4>(2 * n);
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
@@ -128,6 +134,21 @@ int ensure_capacity(bvh_ctx* c, uint32_t n) {
     carve(c, p, n, &total);
     HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)n * sizeof(u64), c->stream));   // HPLOC dependency words: clean once, builds keep them clean
     HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)n * sizeof(u32), c->stream));    // two-pass LBVH exchange words: likewise
+    return 0;
+}
+
+// re-initialise the self-cleaning emit scratch after a build that did not run to completion (see bvh_ctx::scratch_dirty)
+int begin_emit(bvh_ctx* c) {
+    if (c->scratch_dirty) {
+        HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)c->cap * sizeof(u64), c->stream));
+        HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)c->cap * sizeof(u32), c->stream));
+    }
+    c->scratch_dirty = true;
+    return 0;
+}
+int end_emit(bvh_ctx* c) {
+    HIP_TRY(hipGetLastError());
+    c->scratch_dirty = false;
     return 0;
 }
 
@@ -319,8 +340,9 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
-    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count);
-    HIP_TRY(hipGetLastError());
+    r = begin_emit(c); if (r) return r;
+    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count);
+    r = end_emit(c); if (r) return r;
     if (root_out) { HIP_TRY(hipMemcpyAsync(root_out, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return 0;
 }
@@ -330,9 +352,10 @@ int bvh_emit_lbvh_two(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_so
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
+    r = begin_emit(c); if (r) return r;
     launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags, c->hploc.dep, c->small,
-                    c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count);
-    return herr(hipGetLastError());
+                    c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count);
+    return end_emit(c);
 }
 
 int bvh_emit_ploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorted_vals, uint32_t n, void* d_nodes, void* d_leaves,
@@ -350,8 +373,9 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
     if (!c || !d_prim_aabbs || !d_sorted_keys || !d_sorted_vals || !d_nodes || !d_leaves || n < 2) return BVH_E_INVALID_ARG;
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
+    r = begin_emit(c); if (r) return r;
     emit_hploc(c, c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, d_leaves);
-    return herr(hipGetLastError());
+    return end_emit(c);
 }
 
 static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* tm) {
@@ -364,7 +388,10 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
     // E: CalculateSceneExtents (token CalculateCentroidExtentsTime).  The sort's bookkeeping is cleared here so that the
     // Morton kernel can accumulate the digit histograms.
-    const int end_bit = key_bits == 64 ? 60 : 30;              // significant bits of the Morton codes
+    // the reference sorts all 32 key bits at its four call sites (src/Hploc.cpp:63-81 ...); the codes have 30 (60) significant bits, and
+    // sorting the full word costs nothing (4 / 8 passes of 8-bit digits either way) while keeping the fused digit histograms of the Morton
+    // kernel — (code >> 24) & 255 for the last pass — and the sort's digit masks equal for ANY key value
+    const int end_bit = key_bits == 64 ? 64 : 32;
     const int passes = sort_passes(0, end_bit);
     r = stage_extents_valid(in); if (r) return r;
     sort_prepare(s, c->sort, n, passes, c->scene, c->hploc.queue_count, 64 * 32);    // + Aabb::reset of the scene extent + the emitters' queue heads
@@ -380,17 +407,18 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
     // B: hierarchy emit (token BvhBuildTime; SetupClusters is booked here, not under Morton as the reference does)
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
+    r = begin_emit(c); if (r) return r;
     switch (algo) {
-        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
+        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags, c->hploc.dep, c->small,
-                                                  c->ploc.list0, 2 * (size_t)c->cap, c->hploc.queue_count, true); break;
+                                                  c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true); break;
         case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, n);
                                   r = run_ploc(c, n, c->nodes, c->leaves, c->boxes, c->svals, c->ploc, &ploc_iters); if (r) return r;
                                   out->d_leaves = c->leaves; out->layout = 1; break;
     }
-    HIP_TRY(hipGetLastError());
+    r = end_emit(c); if (r) return r;
     if (c->kernel_profiling) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)

@@ -139,10 +139,12 @@ __device__ __forceinline__ int clz_u32(u32 v) { return v ? __clz((int)v) : 32; }
 __device__ __forceinline__ int plen(u32 ka, u32 i, u32 kb, u32 j) { return clz_u64((((u64)ka << 32) | i) ^ (((u64)kb << 32) | j)); }
 __device__ __forceinline__ int plen(u64 ka, u32 i, u64 kb, u32 j) { return ka != kb ? clz_u64(ka ^ kb) : 64 + clz_u32(i ^ j); }
 // do the augmented keys of positions i and j share (at least) their first c bits?  == (plen(...) >= c), without the count-leading-zeros:
-// one 64-bit shift of the xor (u32 keys); c >= 1
+// one 64-bit shift of the xor (u32 keys).  c == 0 (the root gap when adjacent keys differ in bit 31: possible for caller-supplied
+// keys through bvh_emit_hploc, never for the 30-bit Morton codes) is an empty prefix, shared by everything: a shift by 64 is undefined
+// (the hardware shifts by 0), so the shift is done in two steps that are each < 64
 __device__ __forceinline__ bool shares_prefix(u32 ka, u32 i, u32 kb, u32 j, int c) {
     const u64 x = ((u64)(ka ^ kb) << 32) | (u64)(i ^ j);
-    return (x >> (64 - c)) == 0ull;
+    return ((x >> 1) >> (63 - c)) == 0ull;
 }
 __device__ __forceinline__ bool shares_prefix(u64 ka, u32 i, u64 kb, u32 j, int c) { return plen(ka, i, kb, j) >= c; }
 template <typename K> struct KeyBits;

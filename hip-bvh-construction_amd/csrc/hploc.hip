@@ -148,6 +148,7 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             // {area bits, neighbour slot}, into BOTH ends' words — LDS atomics (ds_min_u64; a wave's LDS operations execute in order, so the
             // reset below, the atomics and the read-back need no barrier).  The selection costs no VALU work beyond the validity test.
             nn[lane] = ~0ull;
+            compiler_fence();                        // reset, atomics and read-back stay in program order (the LDS executes a wave's operations in order)
 #else
             // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
             // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
@@ -187,6 +188,7 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             }
             // mergeClusters (:126-190)
 #if HP_NN_LDS == 1
+            compiler_fence();
             const int nbr = (int)(u32)nn[lane];
 #else
             const int nbr = (abL <= abR) ? idL : idR;
@@ -644,7 +646,7 @@ static void hpb_config(int* t, int* nt, int* occ) {
 }
 uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return (uint32_t)t; }
 // every tile may queue up to 2T nodes (its own external nodes + the parents of its maximal local ones), tiles >= 128 leaves
-size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SUB + 2) * 2 * 128 * HPQ_SUB; }
+size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SUB + 6) * 2 * 128 * HPQ_SUB; }
 
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared) {

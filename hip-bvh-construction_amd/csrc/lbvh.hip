@@ -145,7 +145,9 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
             const u32 ps = p - g0;
             const int side = as_left ? 0 : 1;                             // park my box, then publish (LDS operations of a wave execute in order)
             s_box[side][0][ps] = box.lx; s_box[side][1][ps] = box.ly; s_box[side][2][ps] = box.lz; s_box[side][3][ps] = box.hx; s_box[side][4][ps] = box.hy; s_box[side][5][ps] = box.hz;
+            compiler_fence();                                             // the compiler may not sink the box stores below the exchange ...
             const u64 other = atomicExch(reinterpret_cast<unsigned long long*>(&s_slot[ps]), (unsigned long long)slot_word(cur, as_left ? i : j));
+            compiler_fence();                                             // ... nor hoist the sibling's box loads above it
             if (other == SLOT_EMPTY) break;                               // first arriver retires
             const u32 sib = (u32)(other >> 32) - 1u, far = (u32)other;
             const Box sb = { s_box[1 - side][0][ps], s_box[1 - side][1][ps], s_box[1 - side][2][ps], s_box[1 - side][3][ps], s_box[1 - side][4][ps], s_box[1 - side][5][ps] };
@@ -290,7 +292,7 @@ static void launch_lbvh_tiles(hipStream_t s, const void* d_boxes, const void* d_
 
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared) {
-    if (!lbvh_use_tiles(n) || !d_queue) {
+    if (!lbvh_use_tiles(n) || !d_queue || queue_capacity < lbvh_queue_capacity(n)) {   // (a tile may queue up to T roots: never run the tile kernel on a smaller queue)
         const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
         KernelScope ks(s, "k_lbvh_single");
         if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_single<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
@@ -306,7 +308,7 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys,
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent, uint32_t* d_flags, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity,
                      uint32_t* d_queue_count, bool heads_cleared) {
-    if (lbvh_use_tiles(n) && d_queue) {
+    if (lbvh_use_tiles(n) && d_queue && queue_capacity >= lbvh_queue_capacity(n)) {
         launch_lbvh_tiles(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_slots, d_root, d_queue, queue_capacity, d_queue_count, heads_cleared, true);
         return;
     }

@@ -63,9 +63,22 @@ def uniform_slice(n_total: int, count: int, seed: int, offset=(0.0, 0.0, 0.0), s
 
 
 def probe_mesh(n: int) -> np.ndarray:
-    """The survey's probe generator: mt19937(1234), per triangle c = (U,U,U) then three vertices
-    c + (U-.5)*.01 per component.  Python loop; only for small known-answer checks."""
-    import random  # noqa: F401  (documented for provenance; numpy's MT19937 with the same seed is used below)
+    """The survey's probe generator (SURVEY.md Appendix A.4), bit for bit: std::mt19937 rng(1234) and
+    std::uniform_real_distribution<float>(0, 1); per triangle c = (U,U,U), then three vertices c + (U-.5)*.01 per component (draw order
+    c.x c.y c.z, then x y z of each vertex).  numpy's RandomState(1234) seeds MT19937 with init_genrand like std::mt19937 does; libstdc++'s
+    uniform_real_distribution<float> draws ONE 32-bit word per value: float(word) / 2^32 (round to nearest), and 1.0 becomes nextafter(1, 0)
+    (std::generate_canonical<float, 24>).  Pins SURVEY.md §8(c)'s known answers (tests/test_oracle_golden.py)."""
+    raw = np.random.RandomState(1234)._bit_generator.random_raw(12 * n).astype(np.uint32)
+    u = raw.astype(np.float32) / np.float32(4294967296.0)
+    u = np.where(u >= np.float32(1.0), np.nextafter(np.float32(1.0), np.float32(0.0)), u).astype(np.float32).reshape(n, 12)
+    c = u[:, 0:3]
+    v = [(c + (u[:, 3 + 3 * k: 6 + 3 * k] - np.float32(0.5)) * np.float32(0.01)).astype(np.float32) for k in range(3)]
+    return _pack(*v)
+
+
+def np_mt_mesh(n: int) -> np.ndarray:
+    """Same shape of mesh from numpy's Generator(MT19937(1234)) doubles (round 1's stand-in for the probe generator; kept because the
+    committed reference-kernel outputs of the golden mesh "probe5000" were produced on it)."""
     rng = np.random.Generator(np.random.MT19937(1234))
     u = rng.random((n, 12)).astype(np.float32)
     c = u[:, 0:3]

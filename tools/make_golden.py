@@ -29,7 +29,8 @@ def golden_meshes(pkg):
     out["uniform5000_s77"] = mg.uniform(5000, 77)
     out["sponza8000_s3"] = mg.sponza_like(8000, 3)
     out["bunny6000_s2"] = mg.bunny_like(6000, 2)
-    out["probe5000"] = mg.probe_mesh(5000)
+    out["probe5000"] = mg.np_mt_mesh(5000)
+    out["a4_probe5000"] = mg.probe_mesh(5000)        # SURVEY.md Appendix A.4 (std::mt19937(1234))
     return out
 
 
