@@ -43,18 +43,22 @@ KERNEL_BYTES_PER_PRIM = {
     "lbvh_two:k_lbvh_block": 183.9, "lbvh_two:k_lbvh_ext": 4.1,
     "k_ploc_iter": 250.0,         # summed over all iterations: SetupClusters 60 (fused into the first iteration) + the iterations' 190
 }
+# bytes per primitive a kernel of THIS implementation must move through HBM itself (its compulsory traffic, not the reference algorithm's):
+# the tile kernel keeps the work lists of its merge tasks in LDS, so its own traffic is R sorted value 4 + key 4 + box gather 24, W PrimRef 28 +
+# one 32-byte node per merge it performs (~0.92 per primitive) + the hand-over records (~11).  Reported next to the SURVEY §8(d) figure.
+KERNEL_OWN_BYTES_PER_PRIM = {"k_hploc_block": 100.0, "k_hploc_ext": 40.0}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed builds (200 x ~1.5 ms: a 0.3 s timed region, so that one slow launch does not move the number)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--algo", default="hploc", choices=["hploc", "ploc", "lbvh_single", "lbvh_two"])
     ap.add_argument("--mesh", default="uniform", choices=["uniform", "bunny", "sponza"])
-    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="triangles of the mesh the CPU baseline is timed on (0 = skip); ~12 s of single-thread work at 5 M")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="triangles of the mesh the CPU baseline is timed on (0 = skip); the whole 10 M mesh is ~25 s of single-thread work")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
 
@@ -103,9 +107,13 @@ def main() -> None:
     lib = pkg.lib()
     import ctypes as C
 
+    gather_events = []
+
     def step():
         builder.build(ctx, d_tris, on_device=True, n=n)
         if world > 1:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)); gather_events.append(ev)
+            ev[0].record(side)
             # root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
             src = builder.result.d_nodes + 32 * builder.result.root + 8
             rc = lib.bvh_dev_copy(ctx.handle, root_box.data_ptr(), src, 24)
@@ -115,6 +123,7 @@ def main() -> None:
             else:
                 host = root_box.cpu(); out = [torch.zeros(6) for _ in range(world)]
                 dist.all_gather(out, host)
+            ev[1].record(side)
 
     def barrier():
         if world > 1:
@@ -137,6 +146,8 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()
+    # all-gather of the root boxes: mean / max over the timed steps on this rank, device time incl. the 24-byte staging copy
+    gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_events[-args.steps:]] if gather_events else []
     if world > 1 and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
         torch.cuda.synchronize()
         assert torch.equal(gathered[6 * rank: 6 * rank + 6], root_box), "all-gather of root AABBs is inconsistent"
@@ -173,6 +184,9 @@ def main() -> None:
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms_sum / launches, 4), "launches_per_step": launches_per_build,
                 "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_build, 1.0) if name == "k_onesweep" else alg_bytes}
+        if name in KERNEL_OWN_BYTES_PER_PRIM:     # the same kernel against the bytes it really has to move (work lists stay in LDS)
+            own = KERNEL_OWN_BYTES_PER_PRIM[name] * n
+            roof["own_bytes_per_launch"] = own; roof["own_frac"] = round(own / (per_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     # ---- CPU baseline: reference's binned-SAH builder (oracle port), single thread, bounded sample of the same mesh
     cpu = None
     if args.cpu_sample > 0:
@@ -183,7 +197,7 @@ def main() -> None:
         nodes, total = orc.binned_sah_build(sample)
         dt = time.perf_counter() - t0
         cpu = {"value": round(m / dt / 1e6, 4), "unit": "Mtris/s", "cores": 1, "kind": "port",
-               "sample": f"first {m} triangles of the benchmark mesh, oracle port of SahBvh::build (src/BinnedSahBvh.cpp:13-203), {dt:.1f} s",
+               "sample": (f"the whole {m}-triangle benchmark mesh" if m == n else f"first {m} triangles of the benchmark mesh") + f", oracle port of SahBvh::build (src/BinnedSahBvh.cpp:13-203), {dt:.1f} s",
                "sah": round(orc.sah_binned(nodes, total, m)[0], 4)}
     out = {
         "metric": "bvh_build_throughput", "value": round(value, 2), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,6 +212,7 @@ def main() -> None:
                               "achieved_GBs": round(builder.timings.bytes_algorithmic / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac": round(builder.timings.bytes_algorithmic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": roof, "cpu_baseline": cpu, "mesh_gen_s": round(gen_s, 2),
+        "allgather_us": ({"mean": round(float(np.mean(gather_us)), 2), "max": round(float(np.max(gather_us)), 2), "bytes_per_rank": 24} if gather_us else None),
     }
     print(json.dumps(out))
     if world > 1:

@@ -23,7 +23,9 @@ static std::vector<Triangle> makeMesh(size_t n) {   // small deterministic soup 
 template <typename B> static int run(Context& ctx, std::vector<Triangle>& tris, const char* name) {
     B bvh;
     bvh.build(ctx, tris);
-    std::printf("== %s: %zu triangles, root %u, %u internal nodes\n%s", name, tris.size(), bvh.m_rootNodeIdx, bvh.m_nInternalNodes, bvh.perfReport().c_str());
+    std::printf("== %s: %zu triangles, root %u, %u internal nodes, %u wide nodes, BVH2 SAH %g\n", name, tris.size(), bvh.m_rootNodeIdx, bvh.m_nInternalNodes, bvh.m_nWideNodes, bvh.m_costBvh2);
+    std::fflush(stdout);
+    bvh.traverseBvh(ctx);
     const auto nodes = bvh.d_bvhNodes.getData();
     const Aabb& r = nodes[bvh.m_rootNodeIdx].m_aabb;
     std::printf("root aabb [%g %g %g] - [%g %g %g]\n", r.m_min.x, r.m_min.y, r.m_min.z, r.m_max.x, r.m_max.y, r.m_max.z);

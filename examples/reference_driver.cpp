@@ -1,0 +1,86 @@
+// reference_driver.cpp — the body of the reference's driver (src/main.cpp:24-83) compiled against include/bvh/builders.hpp:
+//
+//     Context context;  std::vector<Triangle> triangles;  <load mesh>;
+//     X bvh;  bvh.build(context, triangles);  bvh.traverseBvh(context);
+//
+// for X = TwoPassLbvh / SinglePassLbvh / PLOCNew / HPLOC (the reference picks one with a #define, here argv[1]) and the batched builder.
+// The mesh comes from a raw little-endian f32 file of n x 9 floats (tests/golden/*.tri) instead of MeshLoader::loadScene — OBJ parsing is
+// outside the hot path.  With a third argument everything the builder exposes is dumped to that file so that
+// tests/test_cpp_mirror.py can diff it with the ctypes path: this executable is RUN on the GPU box, not only compiled.
+//
+// Usage: reference_driver <two|single|ploc|hploc|batched> <mesh.tri> [dump.bin]
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <vector>
+#include "bvh/builders.hpp"
+
+using namespace BvhConstruction;
+
+static std::vector<Triangle> loadTri(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    const size_t bytes = (size_t)f.tellg(); f.seekg(0);
+    std::vector<float> raw(bytes / 4); f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(raw.size() * 4));
+    std::vector<Triangle> t(raw.size() / 9);
+    for (size_t i = 0; i < t.size(); ++i) {
+        const float* p = raw.data() + 9 * i;
+        t[i].v1 = float3{p[0], p[1], p[2]}; t[i].v2 = float3{p[3], p[4], p[5]}; t[i].v3 = float3{p[6], p[7], p[8]};
+    }
+    return t;
+}
+
+template <typename T> static void put(std::ofstream& o, const std::vector<T>& v) {
+    const uint64_t n = v.size(), sz = sizeof(T);
+    o.write(reinterpret_cast<const char*>(&n), 8); o.write(reinterpret_cast<const char*>(&sz), 8);
+    if (n) o.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(n * sz));
+}
+
+template <typename B> static int run(Context& context, std::vector<Triangle>& triangles, const char* dump) {
+    B bvh;
+    bvh.build(context, triangles);
+    bvh.traverseBvh(context);
+    if (dump) {   // sections: header words, nodes, leaves, sorted keys, sorted values, unsorted keys, values, prim aabbs, scene, triangles, wide nodes, wide leaves, image
+        std::ofstream o(dump, std::ios::binary);
+        const std::vector<float> head = {(float)bvh.m_rootNodeIdx, (float)bvh.m_nInternalNodes, bvh.m_cost, bvh.m_costBvh2, (float)bvh.m_nWideNodes,
+                                         bvh.m_timer.getTimeRecord(CalculateCentroidExtentsTime), bvh.m_timer.getTimeRecord(CalculateMortonCodesTime),
+                                         bvh.m_timer.getTimeRecord(SortingTime), bvh.m_timer.getTimeRecord(BvhBuildTime), bvh.m_timer.getTimeRecord(CollapseBvhTime),
+                                         (float)bvh.m_width, (float)bvh.m_height};
+        put(o, head);
+        put(o, bvh.d_bvhNodes.getData()); put(o, bvh.d_leafNodes.getData());
+        put(o, bvh.d_sortedMortonCodeKeys.getData()); put(o, bvh.d_sortedMortonCodeValues.getData());
+        put(o, bvh.d_mortonCodeKeys.getData()); put(o, bvh.d_mortonCodeValues.getData());
+        put(o, bvh.d_triangleAabb.getData()); put(o, bvh.d_sceneExtents.getData()); put(o, bvh.d_triangleBuff.getData());
+        put(o, bvh.d_wideBvhNodes.getData(bvh.m_nWideNodes)); put(o, bvh.d_wideLeafNodes.getData());
+        put(o, bvh.m_colorBuffer);
+    }
+    return 0;
+}
+
+int main(int argc, char* argv[]) {
+    try {
+        if (argc < 3) { std::cerr << "usage: reference_driver <two|single|ploc|hploc|batched> <mesh.tri> [dump.bin]\n"; return 2; }
+        Context context;
+        std::vector<Triangle> triangles = loadTri(argv[2]);
+        const char* dump = argc > 3 ? argv[3] : nullptr;
+        if (!std::strcmp(argv[1], "batched")) {            // src/main.cpp:33-50 (many copies of one mesh)
+            BatchedBvhBuilder bvh;
+            std::vector<BatchedBuildInput> batches(4);
+            for (auto& b : batches) b.m_primitives = triangles;
+            bvh.build(context, batches);
+            bvh.traverseBvh(context);
+            for (size_t m = 1; m < batches.size(); ++m) if (bvh.m_checksums[m] != bvh.m_checksums[0]) { std::cerr << "batched trees differ\n"; return 3; }
+            return 0;
+        }
+        if (!std::strcmp(argv[1], "single")) return run<SinglePassLbvh>(context, triangles, dump);
+        if (!std::strcmp(argv[1], "two")) return run<TwoPassLbvh>(context, triangles, dump);
+        if (!std::strcmp(argv[1], "ploc")) return run<PLOCNew>(context, triangles, dump);
+        if (!std::strcmp(argv[1], "hploc")) return run<HPLOC>(context, triangles, dump);
+        std::cerr << "unknown builder " << argv[1] << "\n";
+        return 2;
+    } catch (std::exception& e) {
+        std::cerr << e.what();
+        return -1;
+    }
+}

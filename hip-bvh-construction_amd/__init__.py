@@ -62,6 +62,7 @@ EXPORTS = [
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_build_ex", "bvh_stage_extents", "bvh_stage_extents_ex",
     "bvh_stage_morton", "bvh_stage_morton64", "bvh_sort_pairs", "bvh_sort_pairs64",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_trace", "bvh_sah_cost",
+    "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_destroy",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
 
@@ -79,7 +80,14 @@ class Timings(C.Structure):
 class Result(C.Structure):
     _fields_ = [("d_nodes", C.c_void_p), ("d_leaves", C.c_void_p), ("d_prim_aabbs", C.c_void_p), ("d_scene_extent", C.c_void_p),
                 ("d_sorted_keys", C.c_void_p), ("d_sorted_vals", C.c_void_p), ("root", C.c_uint32), ("n_internal", C.c_uint32),
-                ("n_leaves", C.c_uint32), ("layout", C.c_uint32), ("key_bits", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_leaves", C.c_uint32), ("layout", C.c_uint32), ("key_bits", C.c_uint32), ("reserved", C.c_uint32),
+                ("d_tris", C.c_void_p), ("d_morton_keys", C.c_void_p)]
+
+
+class BatchReport(C.Structure):
+    """bvh_batch_report"""
+    _fields_ = [("root_aabbs", C.POINTER(C.c_float)), ("build_ms", C.POINTER(C.c_float)), ("checksums", C.POINTER(C.c_uint64)),
+                ("sah", C.POINTER(C.c_double)), ("allgather_us", C.c_float), ("wall_ms", C.c_float)]
 
 
 TRI_PADDED64, TRI_PACKED36, TRI_INDEXED = 0, 1, 2
@@ -143,6 +151,12 @@ def lib() -> C.CDLL:
         "bvh_collapse4": ([vp, C.POINTER(Result), vp, vp, C.POINTER(u32)], i32),
         "bvh_ctx_kernel_times": ([vp, C.c_char_p, u32, C.POINTER(C.c_float), C.POINTER(u32), u32], i32),
         "bvh_version": ([], C.c_char_p),
+        "bvh_bvh4_cost": ([vp, vp, u32, vp, vp, u32, C.POINTER(C.c_double)], i32),
+        "bvh_checksum": ([vp, C.POINTER(Result), C.POINTER(u64)], i32),
+        "bvh_ctx_last_collapse_ms": ([vp, C.POINTER(C.c_float)], i32),
+        "bvh_batch_create": ([i32, C.POINTER(i32), C.POINTER(vp)], i32),
+        "bvh_batch_build": ([vp, i32, C.POINTER(vp), C.POINTER(u32), i32, C.POINTER(BatchReport)], i32),
+        "bvh_batch_destroy": ([vp], None),
     }
     for name, (args, res) in sig.items():
         f = getattr(L, name)
@@ -329,6 +343,27 @@ class _Builder:
         wide.free(); prims.free()
         return out
 
+    def checksum(self) -> int:
+        """bvh_checksum: order-independent 64-bit checksum of nodes + leaves + root (== checksum_host of the downloaded arrays)"""
+        v = C.c_uint64()
+        _check(lib().bvh_checksum(self._ctx.handle, C.byref(self.result), C.byref(v)), "bvh_checksum")
+        return int(v.value)
+
+    def collapse4_cost(self):
+        """the tail of the reference's build(): CollapseToWide4Bvh, then m_cost = Utility::calculatebvh4Cost, both on the device.
+        Returns (BVH4 cost, n_wide, collapse ms)."""
+        n = self.result.n_leaves
+        wide = self._ctx.alloc(n * BVH4_NODE.itemsize); prims = self._ctx.alloc(n * PRIM_NODE.itemsize)
+        nw = C.c_uint32(); cost = C.c_double(); ms = C.c_float()
+        try:
+            _check(lib().bvh_collapse4(self._ctx.handle, C.byref(self.result), wide.ptr, prims.ptr, C.byref(nw)), "bvh_collapse4")
+            _check(lib().bvh_bvh4_cost(self._ctx.handle, wide.ptr, nw.value, prims.ptr, self.result.d_prim_aabbs, n, C.byref(cost)), "bvh_bvh4_cost")
+            lib().bvh_ctx_last_collapse_ms(self._ctx.handle, C.byref(ms))
+        finally:
+            wide.free(); prims.free()
+        self.m_cost = cost.value
+        return cost.value, int(nw.value), float(ms.value)
+
     def render(self, tris_host: np.ndarray, camera: np.ndarray, transform: np.ndarray, width: int = 512, kind: int = 0, counts: bool = False):
         """traverseBvh's image: GenerateRays + traversal of this tree (through the LBVH-layout adapter for PLOC/HPLOC).  kind: 0 while-while,
         1 restart trail, 2 if-if, 3 speculative while-while.  Returns (rgba uint8[width*width*4], rays RAY[width*width])
@@ -385,6 +420,57 @@ def batched_build(meshes, algo: int = ALGO_HPLOC, devices=(0,)):
     roots = np.zeros((m, 6), dtype=np.float32); ms = np.zeros(m, dtype=np.float32)
     _check(lib().bvh_batched_build(len(devices), devs, algo, ptrs, counts, m, roots.ctypes.data_as(C.POINTER(C.c_float)), ms.ctypes.data_as(C.POINTER(C.c_float))), "bvh_batched_build")
     return roots, ms
+
+
+class Batch:
+    """bvh_batch: per-device contexts + RCCL communicator kept across builds (single process, one host thread per device)"""
+
+    def __init__(self, devices=(0,)):
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().bvh_batch_create(len(devices), devs, C.byref(h)), "bvh_batch_create")
+        self.handle = h
+
+    def build(self, meshes, algo: int = ALGO_HPLOC, checksums: bool = True, sah: bool = False) -> dict:
+        m = len(meshes)
+        arrs = [np.ascontiguousarray(t) for t in meshes]
+        ptrs = (C.c_void_p * m)(*[a.ctypes.data for a in arrs]); counts = (C.c_uint32 * m)(*[a.shape[0] for a in arrs])
+        roots = np.zeros((m, 6), dtype=np.float32); ms = np.zeros(m, dtype=np.float32); ck = np.zeros(m, dtype=np.uint64); sh = np.zeros(m, dtype=np.float64)
+        rep = BatchReport(roots.ctypes.data_as(C.POINTER(C.c_float)), ms.ctypes.data_as(C.POINTER(C.c_float)),
+                          ck.ctypes.data_as(C.POINTER(C.c_uint64)) if checksums else None, sh.ctypes.data_as(C.POINTER(C.c_double)) if sah else None, 0.0, 0.0)
+        _check(lib().bvh_batch_build(self.handle, algo, ptrs, counts, m, C.byref(rep)), "bvh_batch_build")
+        return {"root_aabbs": roots, "build_ms": ms, "checksums": ck, "sah": sh, "allgather_us": float(rep.allgather_us), "wall_ms": float(rep.wall_ms)}
+
+    def close(self) -> None:
+        if self.handle:
+            lib().bvh_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def checksum_host(nodes: np.ndarray, leaves, root: int) -> int:
+    """numpy mirror of bvh_checksum (csrc/misc.hip k_checksum)"""
+    M = np.uint64(0xff51afd7ed558ccd); G = np.uint64(0x9E3779B97F4A7C15)
+    def mix(h, w):
+        h = (h ^ w.astype(np.uint64)) * M
+        return h ^ (h >> np.uint64(32))
+    total = np.uint64(0)
+    with np.errstate(over="ignore"):
+        for tag, arr, words in ((1, nodes, 8), (2, leaves, 7)):
+            if arr is None:
+                continue
+            w = np.ascontiguousarray(arr).view(np.uint32).reshape(len(arr), words)
+            h = G * (np.arange(len(arr), dtype=np.uint64) + np.uint64(1)) + np.uint64(tag)
+            for k in range(words):
+                h = mix(h, w[:, k])
+            total = total + h.sum(dtype=np.uint64)
+        total = total + mix(np.array([3], dtype=np.uint64), np.array([root], dtype=np.uint32))[0]
+    return int(total)
 
 
 BUILDERS = {ALGO_TWOPASS: TwoPassLbvh, ALGO_SINGLEPASS: SinglePassLbvh, ALGO_PLOCPP: PLOCNew, ALGO_HPLOC: HPLOC}

@@ -58,7 +58,8 @@ struct bvh_ctx {
     // completion.  Set while an emit is being enqueued, cleared when every launch of it was accepted: a build that failed in between
     // (HIP error, early return) makes the next one re-initialise the words instead of silently producing wrong trees.
     bool scratch_dirty = false;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
+    float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
 };
 
 namespace {
@@ -117,7 +118,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
     c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);
-    c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH, [16..31] camera, [32..47] transform
+    c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH / BVH4 cost, [10..11] u64 checksum, [16..31] camera, [32..47] transform
     c->hploc.zero_parent = c->small + 1;
     *total = k.off;
 }
@@ -283,6 +284,7 @@ int bvh_ctx_kernel_times(bvh_ctx* c, char* names_out, uint32_t names_cap, float*
     if (names_out && names_cap) { std::strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
     return (int)k;
 }
+int bvh_ctx_last_collapse_ms(const bvh_ctx* c, float* ms_out) { if (!c || !ms_out) return BVH_E_INVALID_ARG; *ms_out = c->last_collapse_ms; return 0; }
 int bvh_ctx_synchronize(bvh_ctx* c) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return herr(hipStreamSynchronize(c->stream)); }
 
 int bvh_stage_extents(bvh_ctx* c, const void* d_tris, uint32_t n, void* d_prim_aabbs, void* d_scene_extent) {
@@ -428,6 +430,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = c->scene;
     out->d_sorted_keys = c->skeys; out->d_sorted_vals = c->svals;
     out->n_internal = n - 1; out->n_leaves = n; out->key_bits = (uint32_t)key_bits; out->reserved = 0;
+    out->d_tris = in->tri_format == BVH_TRI_INDEXED ? in->d_vertices : in->d_tris; out->d_morton_keys = c->keys;
     if (tm) {
         std::memset(tm, 0, sizeof *tm);
         tm->bytes_algorithmic = algorithmic_bytes(algo, n);
@@ -486,6 +489,7 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
     uint2* taskq = reinterpret_cast<uint2*>(c->slots);                 // u64[n] scratch, free after a build
     u32* state = c->ploc.state;                                         // >= COLLAPSE_STATE_WORDS words
     static_assert(PLOC_STATE_WORDS >= COLLAPSE_STATE_WORDS, "state scratch");
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[5], s));
     collapse_begin(s, taskq, state, in->root);
     u32 host[COLLAPSE_STATE_WORDS];
     int first = 0;
@@ -497,7 +501,14 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
         HIP_TRY(hipStreamSynchronize(s));
         first += count;
         // done when the last processed level created nothing: allocation counter == start of the next level's snapshot
-        if (host[0] == host[1 + first]) { if (n_wide_out) *n_wide_out = host[0]; return 0; }
+        if (host[0] == host[1 + first]) {
+            if (n_wide_out) *n_wide_out = host[0];
+            if (c->profiling) {   // token CollapseBvhTime (src/TwoPassLbvh.cpp:182), including this implementation's level read-backs
+                HIP_TRY(hipEventRecord(c->ev[6], s)); HIP_TRY(hipEventSynchronize(c->ev[6]));
+                HIP_TRY(hipEventElapsedTime(&c->last_collapse_ms, c->ev[5], c->ev[6]));
+            }
+            return 0;
+        }
     }
     return BVH_E_INTERNAL;
 }
@@ -547,6 +558,29 @@ int bvh_sah_cost(bvh_ctx* c, const bvh_result* in, double* cost_out) {
     launch_sah_cost(c->stream, in->d_nodes, in->d_leaves, in->root, in->n_leaves, (int)in->layout, d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(cost_out, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return herr(hipStreamSynchronize(c->stream));
+}
+
+int bvh_bvh4_cost(bvh_ctx* c, const void* d_bvh4, uint32_t n_wide, const void* d_primnodes, const void* d_prim_aabbs, uint32_t n, double* cost_out) {
+    if (!c || !d_bvh4 || !d_primnodes || !d_prim_aabbs || !cost_out || n < 2 || n_wide == 0 || n_wide > n) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, 2); if (r) return r;
+    double* d = reinterpret_cast<double*>(c->small + 8);
+    launch_bvh4_cost(c->stream, d_bvh4, n_wide, d_primnodes, d_prim_aabbs, n, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(cost_out, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return herr(hipStreamSynchronize(c->stream));
+}
+
+int bvh_checksum(bvh_ctx* c, const bvh_result* in, uint64_t* checksum_out) {
+    if (!c || !in || !checksum_out || !in->d_nodes || in->n_leaves < 2) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, 2); if (r) return r;
+    uint64_t* d = reinterpret_cast<uint64_t*>(c->small + 10);
+    const uint32_t n = in->n_leaves;
+    launch_checksum(c->stream, in->d_nodes, in->layout == 0 ? 2 * n - 1 : n - 1, in->layout == 1 ? in->d_leaves : nullptr, n, in->root, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(checksum_out, d, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     return herr(hipStreamSynchronize(c->stream));
 }
 

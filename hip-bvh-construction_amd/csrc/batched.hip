@@ -6,72 +6,146 @@
 // mesh m is built on devs[m % n_dev] by the ordinary single-GPU path (one host thread + one bvh_ctx per device, no peer
 // traffic, no tree is ever split); afterwards ONE ncclAllGather of the per-device root-AABB slots (RCCL, xGMI) leaves the TLAS
 // input on every device, and device devs[0]'s copy is returned to the host.  24 bytes per mesh: latency-only collective.
+// bvh_batch keeps the contexts (arenas), the communicator and the gather buffers across builds; bvh_batched_build is the one-shot form.
 // (The multi-process flavour — one rank per GPU over torch.distributed — lives in the Python harness: batched.py, bench.py.)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
+#include <new>
 #include <thread>
 #include <vector>
-#include <atomic>
 #include "bvh_mi355x.h"
+
+struct bvh_batch {
+    std::vector<int> devs;
+    std::vector<bvh_ctx*> ctx;
+    std::vector<ncclComm_t> comms;
+    bool comm_ok = false;
+    std::vector<float*> d_send, d_recv;
+    std::vector<hipEvent_t> ev0, ev1;
+    int slots = 0;                       // root-box slots per device the gather buffers are sized for
+};
+
+namespace {
+int batch_reserve_slots(bvh_batch* b, int slots) {
+    if (slots <= b->slots) return 0;
+    const int n_dev = (int)b->devs.size();
+    for (int d = 0; d < n_dev; ++d) {
+        if (hipSetDevice(b->devs[d]) != hipSuccess) return BVH_E_INTERNAL;
+        if (b->d_send[d]) (void)hipFree(b->d_send[d]);
+        if (b->d_recv[d]) (void)hipFree(b->d_recv[d]);
+        b->d_send[d] = b->d_recv[d] = nullptr;
+        if (hipMalloc(&b->d_send[d], (size_t)slots * 6 * sizeof(float)) != hipSuccess) return BVH_E_INTERNAL;
+        if (hipMalloc(&b->d_recv[d], (size_t)slots * n_dev * 6 * sizeof(float)) != hipSuccess) return BVH_E_INTERNAL;
+    }
+    b->slots = slots;
+    return 0;
+}
+}  // namespace
+
+extern "C" int bvh_batch_create(int n_dev, const int* devs, bvh_batch** out) {
+    if (n_dev <= 0 || !devs || !out) return BVH_E_INVALID_ARG;
+    *out = nullptr;
+    bvh_batch* b = new (std::nothrow) bvh_batch();
+    if (!b) return BVH_E_INTERNAL;
+    b->devs.assign(devs, devs + n_dev);
+    b->ctx.assign(n_dev, nullptr); b->comms.resize(n_dev); b->d_send.assign(n_dev, nullptr); b->d_recv.assign(n_dev, nullptr);
+    b->ev0.assign(n_dev, nullptr); b->ev1.assign(n_dev, nullptr);
+    int rc = 0;
+    for (int d = 0; d < n_dev && !rc; ++d) {
+        rc = bvh_ctx_create(devs[d], &b->ctx[d]);
+        if (!rc && (hipSetDevice(devs[d]) != hipSuccess || hipEventCreate(&b->ev0[d]) != hipSuccess || hipEventCreate(&b->ev1[d]) != hipSuccess)) rc = BVH_E_INTERNAL;
+    }
+    if (!rc) { if (ncclCommInitAll(b->comms.data(), n_dev, devs) != ncclSuccess) rc = BVH_E_INTERNAL; else b->comm_ok = true; }
+    if (rc) { bvh_batch_destroy(b); return rc; }
+    *out = b;
+    return 0;
+}
+
+extern "C" void bvh_batch_destroy(bvh_batch* b) {
+    if (!b) return;
+    const int n_dev = (int)b->devs.size();
+    for (int d = 0; d < n_dev; ++d) {
+        if (b->comm_ok) ncclCommDestroy(b->comms[d]);
+        (void)hipSetDevice(b->devs[d]);
+        if (b->d_send[d]) (void)hipFree(b->d_send[d]);
+        if (b->d_recv[d]) (void)hipFree(b->d_recv[d]);
+        if (b->ev0[d]) (void)hipEventDestroy(b->ev0[d]);
+        if (b->ev1[d]) (void)hipEventDestroy(b->ev1[d]);
+        if (b->ctx[d]) bvh_ctx_destroy(b->ctx[d]);
+    }
+    delete b;
+}
+
+extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h_tris, const uint32_t* n_tris, int n_meshes, bvh_batch_report* rep) {
+    if (!b || !h_tris || !n_tris || n_meshes <= 0 || !rep || !rep->root_aabbs) return BVH_E_INVALID_ARG;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int n_dev = (int)b->devs.size();
+    const int slots = (n_meshes + n_dev - 1) / n_dev;
+    int rc = batch_reserve_slots(b, slots); if (rc) return rc;
+    std::atomic<int> err{0};
+    auto fail = [&](int code) { int z = 0; err.compare_exchange_strong(z, code); };
+    // ---- builds: one host thread per device, meshes d, d + n_dev, ... on device d
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_dev; ++d) th.emplace_back([&, d]() {
+        bvh_ctx* c = b->ctx[d];
+        if (hipSetDevice(b->devs[d]) != hipSuccess) return fail(BVH_E_INTERNAL);
+        bvh_ctx_set_profiling(c, rep->build_ms ? 1 : 0);
+        if (hipMemsetAsync(b->d_send[d], 0, (size_t)slots * 6 * sizeof(float), (hipStream_t)bvh_ctx_stream(c)) != hipSuccess) return fail(BVH_E_INTERNAL);
+        int k = 0;
+        for (int m = d; m < n_meshes; m += n_dev, ++k) {
+            bvh_result r; bvh_timings t;
+            int rc2 = bvh_build(c, algo, h_tris[m], n_tris[m], 0, &r, &t); if (rc2) return fail(rc2);
+            if (rep->build_ms) rep->build_ms[m] = t.ms_total;
+            // root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
+            rc2 = bvh_dev_copy(c, b->d_send[d] + 6 * k, (const char*)r.d_nodes + 32 * (size_t)r.root + 8, 24); if (rc2) return fail(rc2);
+            if (rep->checksums) { rc2 = bvh_checksum(c, &r, &rep->checksums[m]); if (rc2) return fail(rc2); }
+            if (rep->sah) { rc2 = bvh_sah_cost(c, &r, &rep->sah[m]); if (rc2) return fail(rc2); }
+        }
+        const int rc2 = bvh_ctx_synchronize(c); if (rc2) return fail(rc2);
+    });
+    for (auto& t : th) t.join();
+    rc = err.load();
+    // ---- the only collective: all-gather of the root-AABB slots
+    if (!rc) {
+        ncclGroupStart();
+        for (int d = 0; d < n_dev; ++d) {
+            (void)hipSetDevice(b->devs[d]);
+            hipStream_t s = (hipStream_t)bvh_ctx_stream(b->ctx[d]);
+            (void)hipEventRecord(b->ev0[d], s);
+            if (ncclAllGather(b->d_send[d], b->d_recv[d], (size_t)slots * 6, ncclFloat, b->comms[d], s) != ncclSuccess) rc = BVH_E_INTERNAL;
+            (void)hipEventRecord(b->ev1[d], s);
+        }
+        ncclGroupEnd();
+        for (int d = 0; d < n_dev && !rc; ++d) rc = bvh_ctx_synchronize(b->ctx[d]);
+        float worst = 0.f;
+        for (int d = 0; d < n_dev && !rc; ++d) {
+            float ms = 0.f; (void)hipSetDevice(b->devs[d]);
+            if (hipEventElapsedTime(&ms, b->ev0[d], b->ev1[d]) == hipSuccess && ms > worst) worst = ms;
+        }
+        rep->allgather_us = worst * 1000.f;
+    }
+    if (!rc) {
+        std::vector<float> host((size_t)slots * n_dev * 6);
+        (void)hipSetDevice(b->devs[0]);
+        if (hipMemcpy(host.data(), b->d_recv[0], host.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = BVH_E_INTERNAL;
+        for (int m = 0; m < n_meshes && !rc; ++m) {
+            const int d = m % n_dev, k = m / n_dev;
+            for (int c = 0; c < 6; ++c) rep->root_aabbs[6 * m + c] = host[((size_t)d * slots + k) * 6 + c];
+        }
+    }
+    rep->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+}
 
 extern "C" int bvh_batched_build(int n_dev, const int* devs, bvh_algo algo, const void* const* h_tris, const uint32_t* n_tris, int n_meshes,
                                  float* root_aabbs_out, float* build_ms_out) {
     if (n_dev <= 0 || !devs || !h_tris || !n_tris || n_meshes <= 0 || !root_aabbs_out) return BVH_E_INVALID_ARG;
-    const int slots = (n_meshes + n_dev - 1) / n_dev;
-    std::vector<bvh_ctx*> ctx(n_dev, nullptr);
-    std::vector<float*> d_send(n_dev, nullptr), d_recv(n_dev, nullptr);
-    std::atomic<int> err{0};
-    auto fail = [&](int code) { int z = 0; err.compare_exchange_strong(z, code); };
-    // ---- builds: one host thread per device
-    std::vector<std::thread> th;
-    for (int d = 0; d < n_dev; ++d) th.emplace_back([&, d]() {
-        int rc = bvh_ctx_create(devs[d], &ctx[d]); if (rc) return fail(rc);
-        bvh_ctx_set_profiling(ctx[d], build_ms_out ? 1 : 0);
-        if (hipSetDevice(devs[d]) != hipSuccess) return fail(BVH_E_INTERNAL);
-        if (hipMalloc(&d_send[d], (size_t)slots * 6 * sizeof(float)) != hipSuccess || hipMalloc(&d_recv[d], (size_t)slots * n_dev * 6 * sizeof(float)) != hipSuccess) return fail(BVH_E_INTERNAL);
-        if (hipMemset(d_send[d], 0, (size_t)slots * 6 * sizeof(float)) != hipSuccess) return fail(BVH_E_INTERNAL);
-        int k = 0;
-        for (int m = d; m < n_meshes; m += n_dev, ++k) {
-            bvh_result r; bvh_timings t;
-            rc = bvh_build(ctx[d], algo, h_tris[m], n_tris[m], 0, &r, &t); if (rc) return fail(rc);
-            if (build_ms_out) build_ms_out[m] = t.ms_total;
-            // root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
-            rc = bvh_dev_copy(ctx[d], d_send[d] + 6 * k, (const char*)r.d_nodes + 32 * (size_t)r.root + 8, 24); if (rc) return fail(rc);
-        }
-        rc = bvh_ctx_synchronize(ctx[d]); if (rc) return fail(rc);
-    });
-    for (auto& t : th) t.join();
-    int rc = err.load();
-    // ---- the only collective: all-gather of the root-AABB slots
-    std::vector<ncclComm_t> comms(n_dev);
-    bool comm_ok = false;
-    if (!rc) {
-        if (ncclCommInitAll(comms.data(), n_dev, devs) != ncclSuccess) rc = BVH_E_INTERNAL; else comm_ok = true;
-    }
-    if (!rc) {
-        ncclGroupStart();
-        for (int d = 0; d < n_dev; ++d) {
-            (void)hipSetDevice(devs[d]);
-            if (ncclAllGather(d_send[d], d_recv[d], (size_t)slots * 6, ncclFloat, comms[d], (hipStream_t)bvh_ctx_stream(ctx[d])) != ncclSuccess) rc = BVH_E_INTERNAL;
-        }
-        ncclGroupEnd();
-        for (int d = 0; d < n_dev && !rc; ++d) rc = bvh_ctx_synchronize(ctx[d]);
-    }
-    if (!rc) {
-        std::vector<float> host((size_t)slots * n_dev * 6);
-        (void)hipSetDevice(devs[0]);
-        if (hipMemcpy(host.data(), d_recv[0], host.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = BVH_E_INTERNAL;
-        for (int m = 0; m < n_meshes && !rc; ++m) {
-            const int d = m % n_dev, k = m / n_dev;
-            for (int c = 0; c < 6; ++c) root_aabbs_out[6 * m + c] = host[((size_t)d * slots + k) * 6 + c];
-        }
-    }
-    for (int d = 0; d < n_dev; ++d) {
-        if (comm_ok) ncclCommDestroy(comms[d]);
-        (void)hipSetDevice(devs[d]);
-        if (d_send[d]) (void)hipFree(d_send[d]);
-        if (d_recv[d]) (void)hipFree(d_recv[d]);
-        if (ctx[d]) bvh_ctx_destroy(ctx[d]);
-    }
+    bvh_batch* b = nullptr;
+    int rc = bvh_batch_create(n_dev, devs, &b); if (rc) return rc;
+    bvh_batch_report rep{}; rep.root_aabbs = root_aabbs_out; rep.build_ms = build_ms_out;
+    rc = bvh_batch_build(b, algo, h_tris, n_tris, n_meshes, &rep);
+    bvh_batch_destroy(b);
     return rc;
 }

@@ -129,4 +129,7 @@ void launch_trace_kind(hipStream_t s, int kind, const void* d_rays, const void* 
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out);
 void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t root, uint32_t n, int layout, double* d_out /*[1], zeroed inside*/);
 
+void launch_bvh4_cost(hipStream_t s, const void* d_wide, uint32_t n_wide, const void* d_prims, const void* d_prim_boxes, uint32_t n, double* d_out /*[1], zeroed inside*/);
+void launch_checksum(hipStream_t s, const void* d_nodes, uint32_t n_nodes, const void* d_leaves /*may be null*/, uint32_t n_leaves, uint32_t root, uint64_t* d_out /*[1], zeroed inside*/);
+
 } // namespace bvh

@@ -56,6 +56,82 @@ __global__ __launch_bounds__(256) void k_sah(const bvh2_node* __restrict__ nodes
     }
 }
 
+// BVH4 cost, formula of Utility::calculatebvh4Cost (reference src/Utility.cpp:351-396; what m_cost means after X::build, e.g.
+// src/TwoPassLbvh.cpp:196): 1 + sum over wide nodes and their INTERNAL children (child < n-1) of area(child box) / area(root) + sum over
+// the n primitives of area(prim box) / area(root); root box = union of the wide root's child boxes (leaf slots hold the reset box and do
+// not contribute, exactly as the reference's grow() of a default-constructed Aabb).  Terms in f32 as the reference computes them
+// (area * rootInvArea), accumulation in f64 (the reference accumulates in f32 in node-index order, so its last bits depend on its
+// schedule-dependent numbering).
+struct alignas(128) Wide4Rec { bvh_aabb aabb[4]; u32 child[4]; u32 parent; u32 count; u32 pad[2]; };     // Bvh4Node, src/Common.h:560-566
+__global__ __launch_bounds__(256) void k_bvh4_cost(const Wide4Rec* __restrict__ wide, u32 n_wide, const uint2* __restrict__ prims,
+                                                   const bvh_aabb* __restrict__ prim_boxes, u32 n, double* __restrict__ out) {
+    const u32 ni = n - 1;
+    Box rb = box_empty();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (wide[0].child[k] != INV) rb = box_union(rb, box_load(&wide[0].aabb[k]));
+    const float inv = 1.0f / box_area(rb);
+    double acc = 0.0;
+    const u32 stride = gridDim.x * 256;
+    for (u32 g = blockIdx.x * 256 + threadIdx.x; g < n; g += stride) {
+        if (g < n_wide) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const u32 c = wide[g].child[k]; if (c != INV && c < ni) acc += (double)(box_area(box_load(&wide[g].aabb[k])) * inv); }
+        }
+        acc += (double)(box_area(box_load(prim_boxes + prims[g].x)) * inv);
+    }
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) acc += __shfl_xor(acc, m);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0] + red[1] + red[2] + red[3];
+        if (blockIdx.x == 0) t += 1.0;
+        atomicAdd(out, t);
+    }
+}
+
+// Order-independent 64-bit checksum of a build result: sum (mod 2^64) over every node / leaf record of a hash of {array tag, index,
+// the record's dwords}, plus the root index.  Two builds have the same checksum iff (up to hash collisions) their arrays are byte-identical;
+// integer addition commutes, so the value does not depend on the schedule.  Mirrored in numpy by the test harness (checksum_host).
+__device__ __forceinline__ u64 ck_mix(u64 h, u32 w) { h = (h ^ (u64)w) * 0xff51afd7ed558ccdull; return h ^ (h >> 32); }
+__global__ __launch_bounds__(256) void k_checksum(const u32* __restrict__ nodes, u32 n_nodes, const u32* __restrict__ leaves, u32 n_leaves, u32 root,
+                                                  unsigned long long* __restrict__ out) {
+    u64 acc = 0ull;
+    const u32 stride = gridDim.x * 256;
+    const u32 total = n_nodes > n_leaves ? n_nodes : n_leaves;
+    for (u32 g = blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+        if (g < n_nodes) {
+            u64 h = 0x9E3779B97F4A7C15ull * ((u64)g + 1ull) + 1ull;
+            const uint4 a = reinterpret_cast<const uint4*>(nodes)[2 * (size_t)g], b = reinterpret_cast<const uint4*>(nodes)[2 * (size_t)g + 1];
+            h = ck_mix(h, a.x); h = ck_mix(h, a.y); h = ck_mix(h, a.z); h = ck_mix(h, a.w); h = ck_mix(h, b.x); h = ck_mix(h, b.y); h = ck_mix(h, b.z); h = ck_mix(h, b.w);
+            acc += h;
+        }
+        if (leaves && g < n_leaves) {
+            u64 h = 0x9E3779B97F4A7C15ull * ((u64)g + 1ull) + 2ull;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) h = ck_mix(h, leaves[(size_t)g * 7 + k]);
+            acc += h;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out, (unsigned long long)ck_mix(3ull, root));
+}
+
+void launch_bvh4_cost(hipStream_t s, const void* d_wide, uint32_t n_wide, const void* d_prims, const void* d_prim_boxes, uint32_t n, double* d_out) {
+    hipMemsetAsync(d_out, 0, sizeof(double), s);
+    const u32 blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_bvh4_cost, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, s, (const Wide4Rec*)d_wide, n_wide, (const uint2*)d_prims, (const bvh_aabb*)d_prim_boxes, n, d_out);
+}
+void launch_checksum(hipStream_t s, const void* d_nodes, uint32_t n_nodes, const void* d_leaves, uint32_t n_leaves, uint32_t root, uint64_t* d_out) {
+    hipMemsetAsync(d_out, 0, sizeof(uint64_t), s);
+    const u32 total = n_nodes > n_leaves ? n_nodes : n_leaves;
+    const u32 blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_checksum, dim3(blocks < 2048u ? blocks : 2048u), dim3(256), 0, s, (const u32*)d_nodes, n_nodes, (const u32*)d_leaves, d_leaves ? n_leaves : 0u, root, (unsigned long long*)d_out);
+}
+
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out) {
     hipLaunchKernelGGL(k_to_lbvh_layout, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh2_node*)d_nodes, (const bvh_primref*)d_leaves, n, (bvh2_node*)d_out);
 }

@@ -1,17 +1,30 @@
 // builders.hpp — C++ host mirror of the reference's builder API over the C ABI (include/bvh_mi355x.h).
 //
-// Same namespace, class names, method signatures and public result members as the reference, so that a caller of
-//   BvhConstruction::{TwoPassLbvh, SinglePassLbvh, PLOCNew, HPLOC}::build(Context&, std::vector<Triangle>&)
-// (reference src/TwoPassLbvh.h:12-32, src/SinglePassLbvh.h:12-32, src/PLOC++Bvh.h:12-33, src/Hploc.h:12-33; driver
-// src/main.cpp:52-65) recompiles against this header unchanged.  Differences, all documented in INTEGRATION.md:
-//   * d_* members are lightweight views (ptr()/size()/getData()) of ctx-owned device memory instead of Oro::GpuMemory;
+// Same namespace, class names, method signatures and public result members as the reference, so that the body of the reference's
+// driver (src/main.cpp:52-77: `X bvh; bvh.build(context, triangles); bvh.traverseBvh(context);`) compiles and runs against this
+// header (examples/reference_driver.cpp is that body; tests/test_cpp_mirror.py runs it on the GPU and diffs its trees with the ctypes path):
+//   BvhConstruction::{TwoPassLbvh, SinglePassLbvh, PLOCNew, HPLOC}::build(Context&, std::vector<Triangle>&) and ::traverseBvh(Context&)
+//   (src/TwoPassLbvh.h:12-32, src/SinglePassLbvh.h:12-32, src/PLOC++Bvh.h:12-33, src/Hploc.h:12-33).
+// build() does what the reference's build() does on the device: E, M, S, B, then CollapseToWide4Bvh, and m_cost = the BVH4 cost of
+// Utility::calculatebvh4Cost (src/TwoPassLbvh.cpp:154-197).  traverseBvh() is the reference's per-builder flavour: TwoPassLbvh renders
+// 512x512 with the speculative while-while kernel and transformation (0,0,-5)/1 (src/TwoPassLbvh.cpp:199-311), SinglePassLbvh with the
+// if-if kernel and (0,0,-3)/3 (src/SinglePassLbvh.cpp:190-311: IFIF wins its #if chain), PLOCNew / HPLOC only print (src/PLOC++Bvh.cpp:198-212,
+// src/Hploc.cpp:167-181); all print the reference's perf block to std::cout.
+// Differences, all documented in INTEGRATION.md:
+//   * d_* members are lightweight views (ptr()/size()/getData()) of ctx-owned device memory instead of Oro::GpuMemory; they stay valid
+//     until the next build on the same Context.  d_mortonCodeValues is never materialised (value i = i): its getData() returns the iota;
 //   * Context owns a bvh_ctx (device + stream + arena) instead of an Orochi context; device selectable (reference: 0);
-//   * SinglePassLbvh exposes m_rootNodeIdx = the BVH2 root (the reference overwrites it with the BVH4 root 0 before the
-//     BVH2 traversal uses it, src/SinglePassLbvh.cpp:183 vs :265 — a reference bug);
+//   * SinglePassLbvh keeps m_rootNodeIdx = the BVH2 root (the reference overwrites it with the BVH4 root 0 before the BVH2 traversal
+//     uses it, src/SinglePassLbvh.cpp:183 vs :265 — a reference bug); the BVH4 root is always 0;
+//   * the image stays in m_colorBuffer (RGBA8, the reference's d_colorBuffer read-back); no PNG is written (stb is out of scope);
 //   * errors: build() throws std::runtime_error with the C-ABI code (the reference prints and continues).
 // Header-only; link with -lbvh_mi355x.
 #pragma once
+#include <chrono>
+#include <cmath>
 #include <cstdint>
+#include <iostream>
+#include <numeric>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -24,15 +37,31 @@ using u32 = uint32_t; using u8 = uint8_t; using u64 = uint64_t;
 constexpr u32 INVALID_NODE_IDX = BVH_INVALID;   // src/Common.h:90
 constexpr u32 INVALID_PRIM_IDX = BVH_INVALID;   // src/Common.h:91
 constexpr float FltMax = BVH_FLT_MAX;           // src/Common.h:86
+constexpr float Pi = 3.14159265358979323846f;
 
 struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
 struct Aabb { float3 m_min{FltMax, FltMax, FltMax}, m_max{-FltMax, -FltMax, -FltMax};   // src/Common.h:310-416 (data + the helpers hosts use)
     float3 extent() const { return {m_max.x - m_min.x, m_max.y - m_min.y, m_max.z - m_min.z}; }
     float area() const { const float3 e = extent(); return 2 * (e.x * e.y + e.x * e.z + e.y * e.z); } };
 struct alignas(64) Triangle { float3 v1, v2, v3; };                                        // src/Common.h:429-434
 struct alignas(32) Bvh2Node { u32 m_leftChildIdx, m_rightChildIdx; Aabb m_aabb; };         // src/Common.h:436-441
 struct PrimRef { u32 m_primIdx = INVALID_PRIM_IDX; Aabb m_aabb; };                         // src/Common.h:574-578
+struct alignas(32) Ray { float3 m_origin; float3 m_direction; float m_tMin = 0.0f; float m_tMax = FltMax; };                     // :533-539
+struct alignas(64) Transformation { float3 m_translation; float m_pad; float3 m_scale; float m_pad1; float4 m_quat; };           // :541-548
+struct alignas(64) Camera { float4 m_eye; float4 m_quat; float m_fov; float m_near; float m_far; float m_pad; };                 // :550-558
+struct alignas(128) Bvh4Node { Aabb m_aabb[4]; u32 m_child[4] = {INVALID_NODE_IDX, INVALID_NODE_IDX, INVALID_NODE_IDX, INVALID_NODE_IDX};
+                               u32 m_parent = INVALID_NODE_IDX; u32 m_childCount = 2; };                                         // :560-566
+struct PrimNode { u32 m_primIdx = INVALID_PRIM_IDX; u32 m_parent = INVALID_NODE_IDX; };                                          // :568-572
 static_assert(sizeof(Aabb) == 24 && sizeof(Triangle) == 64 && sizeof(Bvh2Node) == 32 && sizeof(PrimRef) == 28, "reference ABI");
+static_assert(sizeof(Ray) == 32 && sizeof(Transformation) == 64 && sizeof(Camera) == 64 && sizeof(Bvh4Node) == 128 && sizeof(PrimNode) == 8, "reference ABI");
+
+inline float4 qtGetIdentity() { return float4{0.0f, 0.0f, 0.0f, 1.0f}; }                  // src/Common.h:474
+inline float4 qtRotation(float4 axisAngle) {                                               // src/Common.h:461-472
+    const float len = std::sqrt(axisAngle.x * axisAngle.x + axisAngle.y * axisAngle.y + axisAngle.z * axisAngle.z);
+    const float s = std::sin(axisAngle.w / 2.0f), c = std::cos(axisAngle.w / 2.0f);
+    return float4{axisAngle.x / len * s, axisAngle.y / len * s, axisAngle.z / len * s, c};
+}
 
 enum TimerCodes { CalculateCentroidExtentsTime, CalculateMortonCodesTime, SortingTime, BvhBuildTime, TraversalTime, CollapseBvhTime, RayGenTime };  // src/Common.h:418-427
 
@@ -59,21 +88,56 @@ private:
 // view of a ctx-owned device array with the read-back call the reference's hosts use (Oro::GpuMemory<T>::getData)
 template <typename T> class DeviceView {
 public:
-    void bind(bvh_ctx* c, void* p, size_t n) { m_ctx = c; m_ptr = static_cast<T*>(p); m_size = n; }
+    void bind(bvh_ctx* c, const void* p, size_t n) { m_ctx = c; m_ptr = static_cast<T*>(const_cast<void*>(p)); m_size = n; }
     T* ptr() const { return m_ptr; }
     size_t size() const { return m_size; }
     std::vector<T> getData() const { std::vector<T> h(m_size); if (m_size) check(bvh_dev_download(m_ctx, h.data(), m_ptr, m_size * sizeof(T)), "getData"); return h; }
 private:
     bvh_ctx* m_ctx = nullptr; T* m_ptr = nullptr; size_t m_size = 0;
 };
+// d_mortonCodeValues: value i = i (src/CommonBlocksKernel.h:384); this pipeline produces the indices inside the first sort pass instead of
+// writing and re-reading 4 bytes per primitive, so there is no device array behind it
+class IotaView {
+public:
+    void bind(size_t n) { m_size = n; }
+    u32* ptr() const { return nullptr; }
+    size_t size() const { return m_size; }
+    std::vector<u32> getData() const { std::vector<u32> h(m_size); std::iota(h.begin(), h.end(), 0u); return h; }
+private:
+    size_t m_size = 0;
+};
+// a device allocation owned by the builder object (the wide tree, the image buffers)
+template <typename T> class DeviceArray {
+public:
+    DeviceArray() = default;
+    DeviceArray(const DeviceArray&) = delete; DeviceArray& operator=(const DeviceArray&) = delete;
+    ~DeviceArray() { reset(); }
+    void resize(bvh_ctx* c, size_t n) { if (n <= m_cap && c == m_ctx) { m_size = n; return; } reset(); m_ctx = c; void* p = nullptr; check(bvh_dev_alloc(c, n * sizeof(T), &p), "bvh_dev_alloc"); m_ptr = static_cast<T*>(p); m_cap = m_size = n; }
+    void reset() { if (m_ptr) bvh_dev_free(m_ctx, m_ptr); m_ptr = nullptr; m_cap = m_size = 0; }
+    T* ptr() const { return m_ptr; }
+    size_t size() const { return m_size; }
+    std::vector<T> getData(size_t count) const { std::vector<T> h(count); if (count) check(bvh_dev_download(m_ctx, h.data(), m_ptr, count * sizeof(T)), "getData"); return h; }
+    std::vector<T> getData() const { return getData(m_size); }
+private:
+    bvh_ctx* m_ctx = nullptr; T* m_ptr = nullptr; size_t m_cap = 0, m_size = 0;
+};
 
 namespace detail {
+// what each reference builder's traverseBvh() does (file:line in the header comment)
+struct TraverseFlavour { bool render; bvh_trace_kind kind; float3 translation; float scale; };
+template <bvh_algo ALGO> constexpr TraverseFlavour flavour() {
+    return ALGO == BVH_LBVH_TWOPASS    ? TraverseFlavour{true, BVH_TRACE_SPECULATIVE_WHILE, {0.0f, 0.0f, -5.0f}, 1.0f}
+         : ALGO == BVH_LBVH_SINGLEPASS ? TraverseFlavour{true, BVH_TRACE_IF_IF, {0.0f, 0.0f, -3.0f}, 3.0f}
+                                       : TraverseFlavour{false, BVH_TRACE_WHILE_WHILE, {0.0f, 0.0f, 0.0f}, 1.0f};
+}
+
 template <bvh_algo ALGO> class Builder {
 public:
     void build(Context& context, std::vector<Triangle>& primitives) {
         const u32 n = static_cast<u32>(primitives.size());
         bvh_result r{}; bvh_timings t{};
         check(bvh_build(context.handle(), ALGO, primitives.data(), n, 0, &r, &t), "build");
+        m_triFormat = BVH_TRI_PADDED64;
         publish(context, r, t, n);
     }
     // beyond the reference (bvh_build_ex): device-resident input in any bvh_tri_format, 30- or 60-bit Morton codes.  With 60-bit codes
@@ -81,61 +145,131 @@ public:
     void build(Context& context, const bvh_build_input& input, u32 n) {
         bvh_result r{}; bvh_timings t{};
         check(bvh_build_ex(context.handle(), ALGO, &input, n, &r, &t), "build_ex");
+        m_triFormat = input.tri_format;
         publish(context, r, t, n);
+    }
+
+    // X::traverseBvh(Context&): GenerateRays -> the traversal kernel this builder's reference source selects -> RGBA read-back -> perf block.
+    void traverseBvh(Context& context) {
+        constexpr TraverseFlavour f = flavour<ALGO>();
+        if (f.render && m_result.d_nodes && m_triFormat == BVH_TRI_PADDED64) {
+            Transformation t{}; t.m_translation = f.translation; t.m_scale = float3{f.scale, f.scale, f.scale}; t.m_quat = qtGetIdentity();
+            Camera cam{}; cam.m_eye = float4{0.0f, 2.5f, 5.8f, 0.0f}; cam.m_quat = qtRotation(float4{0.0f, 0.0f, 1.0f, -1.57f});
+            cam.m_fov = 45.0f * Pi / 180.f; cam.m_near = 0.0f; cam.m_far = 100000.0f;
+            render(context, cam, t, f.kind, 512, 512);
+        }
+        printPerf(std::cout);
+    }
+    // the image part of traverseBvh with caller-chosen view and kernel (any builder; PLOC layouts go through the LBVH-layout adapter)
+    void render(Context& context, const Camera& cam, const Transformation& t, bvh_trace_kind kind, u32 width, u32 height) {
+        bvh_ctx* c = context.handle();
+        const u32 n = m_result.n_leaves;
+        d_rayBuffer.resize(c, size_t(width) * height); d_rayCounterBuffer.resize(c, size_t(width) * height); d_colorBuffer.resize(c, size_t(width) * height * 4);
+        const void* nodes = m_result.d_nodes;
+        if (m_result.layout == 1) { d_lbvhLayoutNodes.resize(c, 2 * size_t(n) - 1); check(bvh_to_lbvh_layout(c, &m_result, d_lbvhLayoutNodes.ptr()), "bvh_to_lbvh_layout"); nodes = d_lbvhLayoutNodes.ptr(); }
+        using clk = std::chrono::steady_clock;           // (Timer::measure brackets each launch with a blocking wait, src/Timer.h:50-52)
+        check(bvh_ctx_synchronize(c), "sync"); const auto t0 = clk::now();
+        check(bvh_generate_rays(c, &cam, d_rayBuffer.ptr(), width, height), "GenerateRays");
+        check(bvh_ctx_synchronize(c), "sync"); const auto t1 = clk::now();
+        check(bvh_trace(c, kind, d_rayBuffer.ptr(), m_result.d_tris, nodes, m_rootNodeIdx, m_nInternalNodes, &t, d_colorBuffer.ptr(), d_rayCounterBuffer.ptr(), width, height), "traversal");
+        check(bvh_ctx_synchronize(c), "sync"); const auto t2 = clk::now();
+        m_timer.set(RayGenTime, std::chrono::duration<float, std::milli>(t1 - t0).count());
+        m_timer.set(TraversalTime, std::chrono::duration<float, std::milli>(t2 - t1).count());
+        m_colorBuffer = d_colorBuffer.getData();
+        m_width = width; m_height = height;
+    }
+    void printPerf(std::ostream& os) const {      // src/TwoPassLbvh.cpp:300-310
+        os << "==========================Perf Times==========================" << std::endl;
+        os << "CalculateCentroidExtentsTime :" << m_timer.getTimeRecord(CalculateCentroidExtentsTime) << "ms" << std::endl;
+        os << "CalculateMortonCodesTime :" << m_timer.getTimeRecord(CalculateMortonCodesTime) << "ms" << std::endl;
+        os << "SortingTime : " << m_timer.getTimeRecord(SortingTime) << "ms" << std::endl;
+        os << "BvhBuildTime : " << m_timer.getTimeRecord(BvhBuildTime) << "ms" << std::endl;
+        os << "TraversalTime : " << m_timer.getTimeRecord(TraversalTime) << "ms" << std::endl;
+        os << "CollapseTime : " << m_timer.getTimeRecord(CollapseBvhTime) << "ms" << std::endl;
+        os << "Bvh Cost : " << m_cost << std::endl;
+        os << "Total Time : " << m_timer.getTimeRecord(CalculateCentroidExtentsTime) + m_timer.getTimeRecord(CalculateMortonCodesTime) +
+                  m_timer.getTimeRecord(SortingTime) + m_timer.getTimeRecord(BvhBuildTime) << "ms" << std::endl;
+        os << "==============================================================" << std::endl;
     }
 private:
     void publish(Context& context, const bvh_result& r, const bvh_timings& t, u32 n) {
+        bvh_ctx* c = context.handle();
         m_result = r;
         const size_t nodes = r.layout == 0 ? 2 * size_t(n) - 1 : size_t(n) - 1;
-        d_bvhNodes.bind(context.handle(), r.d_nodes, nodes);
-        d_leafNodes.bind(context.handle(), r.d_leaves, r.d_leaves ? n : 0);
-        d_triangleAabb.bind(context.handle(), r.d_prim_aabbs, n);
-        d_sceneExtents.bind(context.handle(), r.d_scene_extent, 1);
-        d_sortedMortonCodeKeys.bind(context.handle(), r.key_bits == 64 ? nullptr : r.d_sorted_keys, r.key_bits == 64 ? 0 : n);
-        d_sortedMortonCodeKeys64.bind(context.handle(), r.key_bits == 64 ? r.d_sorted_keys : nullptr, r.key_bits == 64 ? n : 0);
-        d_sortedMortonCodeValues.bind(context.handle(), r.d_sorted_vals, n);
+        d_triangleBuff.bind(c, m_triFormat == BVH_TRI_PADDED64 ? r.d_tris : nullptr, m_triFormat == BVH_TRI_PADDED64 ? n : 0);
+        d_bvhNodes.bind(c, r.d_nodes, nodes);
+        d_leafNodes.bind(c, r.d_leaves, r.d_leaves ? n : 0);
+        d_triangleAabb.bind(c, r.d_prim_aabbs, n);
+        d_sceneExtents.bind(c, r.d_scene_extent, 1);
+        d_sortedMortonCodeKeys.bind(c, r.key_bits == 64 ? nullptr : r.d_sorted_keys, r.key_bits == 64 ? 0 : n);
+        d_sortedMortonCodeKeys64.bind(c, r.key_bits == 64 ? r.d_sorted_keys : nullptr, r.key_bits == 64 ? n : 0);
+        d_sortedMortonCodeValues.bind(c, r.d_sorted_vals, n);
+        d_mortonCodeKeys.bind(c, r.key_bits == 64 ? nullptr : r.d_morton_keys, r.key_bits == 64 ? 0 : n);
+        d_mortonCodeKeys64.bind(c, r.key_bits == 64 ? r.d_morton_keys : nullptr, r.key_bits == 64 ? n : 0);
+        d_mortonCodeValues.bind(n);
         m_rootNodeIdx = r.root; m_nInternalNodes = r.n_internal;
         m_timer.set(CalculateCentroidExtentsTime, t.ms_extents); m_timer.set(CalculateMortonCodesTime, t.ms_morton);
-        m_timer.set(SortingTime, t.ms_sort); m_timer.set(BvhBuildTime, t.ms_build); m_timer.set(CollapseBvhTime, t.ms_collapse);
-        double c = 0; check(bvh_sah_cost(context.handle(), &r, &c), "bvh_sah_cost"); m_cost = static_cast<float>(c);   // BVH2 SAH (the reference reports the BVH4 cost)
+        m_timer.set(SortingTime, t.ms_sort); m_timer.set(BvhBuildTime, t.ms_build);
+        double c2 = 0; check(bvh_sah_cost(c, &r, &c2), "bvh_sah_cost"); m_costBvh2 = static_cast<float>(c2);
+        // CollapseToWide4Bvh + m_cost = calculatebvh4Cost (src/TwoPassLbvh.cpp:154-197)
+        d_wideBvhNodes.resize(c, n); d_wideLeafNodes.resize(c, n);
+        check(bvh_collapse4(c, &r, d_wideBvhNodes.ptr(), d_wideLeafNodes.ptr(), &m_nWideNodes), "bvh_collapse4");
+        float cms = 0.f; bvh_ctx_last_collapse_ms(c, &cms); m_timer.set(CollapseBvhTime, cms);
+        double c4 = 0; check(bvh_bvh4_cost(c, d_wideBvhNodes.ptr(), m_nWideNodes, d_wideLeafNodes.ptr(), r.d_prim_aabbs, n, &c4), "bvh_bvh4_cost");
+        m_cost = static_cast<float>(c4);
     }
+    u32 m_triFormat = BVH_TRI_PADDED64;
 public:
-    // the reference's traverseBvh() prints the perf block (src/TwoPassLbvh.cpp:300-310); the PLOC/HPLOC flavours do nothing else
-    std::string perfReport() const {
-        auto f = [&](int tok) { return std::to_string(m_timer.getTimeRecord(tok)); };
-        const float total = m_timer.getTimeRecord(CalculateCentroidExtentsTime) + m_timer.getTimeRecord(CalculateMortonCodesTime) + m_timer.getTimeRecord(SortingTime) + m_timer.getTimeRecord(BvhBuildTime);
-        return "CalculateCentroidExtentsTime :" + f(CalculateCentroidExtentsTime) + "ms\nCalculateMortonCodesTime :" + f(CalculateMortonCodesTime) + "ms\nSortingTime : " + f(SortingTime) +
-               "ms\nBvhBuildTime : " + f(BvhBuildTime) + "ms\nBvh Cost : " + std::to_string(m_cost) + "\nTotal Time : " + std::to_string(total) + "ms\n";
-    }
+    // the reference's public members (src/Hploc.h:19-32, src/TwoPassLbvh.h:19-31)
+    DeviceView<Triangle> d_triangleBuff;                                   // (bound for 64-byte Triangle inputs only)
     DeviceView<Aabb> d_triangleAabb, d_sceneExtents;
+    DeviceView<u32> d_mortonCodeKeys;
+    IotaView d_mortonCodeValues;
     DeviceView<u32> d_sortedMortonCodeKeys, d_sortedMortonCodeValues;
-    DeviceView<uint64_t> d_sortedMortonCodeKeys64;
+    DeviceView<uint64_t> d_mortonCodeKeys64, d_sortedMortonCodeKeys64;     // 60-bit builds (beyond the reference)
     DeviceView<Bvh2Node> d_bvhNodes;
     DeviceView<PrimRef> d_leafNodes;
     u32 m_rootNodeIdx = 0;
     Timer m_timer;
     u32 m_nInternalNodes = 0;
-    float m_cost = 0.0f;
+    float m_cost = 0.0f;                 // BVH4 cost (Utility::calculatebvh4Cost), as in the reference after build()
+    // beyond the reference's members
+    float m_costBvh2 = 0.0f;             // BVH2 SAH (Utility::calculateLbvhCost formula)
+    u32 m_nWideNodes = 0;                // wide nodes of the collapsed tree (root 0)
+    DeviceArray<Bvh4Node> d_wideBvhNodes; DeviceArray<PrimNode> d_wideLeafNodes;      // locals of the reference's build(), kept here
+    DeviceArray<Ray> d_rayBuffer; DeviceArray<u32> d_rayCounterBuffer; DeviceArray<u8> d_colorBuffer; DeviceArray<Bvh2Node> d_lbvhLayoutNodes;
+    std::vector<u8> m_colorBuffer; u32 m_width = 0, m_height = 0;                      // the image traverseBvh() rendered (RGBA8)
     bvh_result m_result{};
 };
 }  // namespace detail
 
-// src/BatchedBuilder.h:12-31, re-purposed as the scene shard of BASELINE.json config 5: one mesh per GPU, RCCL all-gather of roots
+// src/BatchedBuilder.h:12-31, re-purposed as the scene shard of BASELINE.json config 5: one mesh per GPU, RCCL all-gather of roots.
+// The per-device contexts and the communicator live as long as the object (bvh_batch).
 struct BatchedBuildInput { std::vector<Triangle> m_primitives; };
 class BatchedBvhBuilder {
 public:
     explicit BatchedBvhBuilder(std::vector<int> devices = {0}, bvh_algo algo = BVH_HPLOC) : m_devices(std::move(devices)), m_algo(algo) {}
+    ~BatchedBvhBuilder() { if (m_batch) bvh_batch_destroy(m_batch); }
+    BatchedBvhBuilder(const BatchedBvhBuilder&) = delete; BatchedBvhBuilder& operator=(const BatchedBvhBuilder&) = delete;
     void build(Context&, std::vector<BatchedBuildInput>& batch) {
+        if (!m_batch) check(bvh_batch_create((int)m_devices.size(), m_devices.data(), &m_batch), "bvh_batch_create");
         std::vector<const void*> ptrs; std::vector<uint32_t> counts;
         for (auto& b : batch) { ptrs.push_back(b.m_primitives.data()); counts.push_back((uint32_t)b.m_primitives.size()); }
-        m_rootAabbs.assign(batch.size(), Aabb{}); m_buildMs.assign(batch.size(), 0.f);
-        check(bvh_batched_build((int)m_devices.size(), m_devices.data(), m_algo, ptrs.data(), counts.data(), (int)batch.size(),
-                                reinterpret_cast<float*>(m_rootAabbs.data()), m_buildMs.data()), "bvh_batched_build");
+        m_rootAabbs.assign(batch.size(), Aabb{}); m_buildMs.assign(batch.size(), 0.f); m_checksums.assign(batch.size(), 0);
+        bvh_batch_report rep{}; rep.root_aabbs = reinterpret_cast<float*>(m_rootAabbs.data()); rep.build_ms = m_buildMs.data(); rep.checksums = m_checksums.data();
+        check(bvh_batch_build(m_batch, m_algo, ptrs.data(), counts.data(), (int)batch.size(), &rep), "bvh_batch_build");
+        m_allGatherUs = rep.allgather_us; m_wallMs = rep.wall_ms;
+    }
+    void traverseBvh(Context&) {   // (the reference's flavour renders one of its tiny trees; here: the per-mesh report)
+        for (size_t m = 0; m < m_buildMs.size(); ++m) std::cout << "mesh " << m << " build " << m_buildMs[m] << "ms" << std::endl;
+        std::cout << "root AABB all-gather " << m_allGatherUs << "us" << std::endl;
     }
     std::vector<Aabb> m_rootAabbs;      // TLAS input: one root box per mesh, identical on every device after the all-gather
     std::vector<float> m_buildMs;
+    std::vector<uint64_t> m_checksums;  // bvh_checksum of every mesh's tree
+    float m_allGatherUs = 0.f, m_wallMs = 0.f;
 private:
-    std::vector<int> m_devices; bvh_algo m_algo;
+    std::vector<int> m_devices; bvh_algo m_algo; bvh_batch* m_batch = nullptr;
 };
 
 class TwoPassLbvh : public detail::Builder<BVH_LBVH_TWOPASS> {};        // src/TwoPassLbvh.h:12-32

@@ -82,6 +82,10 @@ typedef struct {
     uint32_t layout;              /* 0 = LBVH layout, 1 = PLOC layout */
     uint32_t key_bits;            /* 32: d_sorted_keys is u32[n] (30-bit codes, the reference); 64: u64[n] (60-bit codes, bvh_build_ex) */
     uint32_t reserved;
+    const void* d_tris;           /* the triangles the build read, on the device (d_triangleBuff): the ctx's H2D copy of a host input, or the
+                                     caller's own device buffer; format as given to the build (Triangle[n] for bvh_build) */
+    void*    d_morton_keys;       /* unsorted Morton codes by primitive index, u32[n] / u64[n] (d_mortonCodeKeys).  d_mortonCodeValues is
+                                     not materialised: value i = i (src/CommonBlocksKernel.h:384), produced inside the first sort pass */
 } bvh_result;
 
 /* X::build(Context&, std::vector<Triangle>&).  tris: Triangle[n], 64-byte stride, host (tris_on_device = 0: copied H2D
@@ -151,6 +155,8 @@ int  bvh_to_lbvh_layout(bvh_ctx* ctx, const bvh_result* in, void* d_nodes_2n_min
  * BVH2 -> BVH4.  d_bvh4: Bvh4Node[n] (128 B each, src/Common.h:560-566), d_primnodes: PrimNode[n] (src/Common.h:568-572);
  * wide root = node 0; *n_wide_out = number of wide nodes.  Blocking (reads the level bounds back). */
 int  bvh_collapse4(bvh_ctx* ctx, const bvh_result* in, void* d_bvh4, void* d_primnodes, uint32_t* n_wide_out);
+/* duration of the last bvh_collapse4 on this ctx (the reference's CollapseBvhTime token); 0 unless profiling was on */
+int  bvh_ctx_last_collapse_ms(const bvh_ctx* ctx, float* ms_out);
 /* ---- consumer side used by the image check ---- */
 /* GenerateRays (src/CommonBlocksKernel.h:432-463).  h_camera: 64-byte Camera record (src/Common.h:550-558) on the host;
  * d_rays: Ray[width*height] (32 bytes each, src/Common.h:533-539), ray of pixel (gx,gy) at index gx*height+gy. */
@@ -170,6 +176,14 @@ int  bvh_trace(bvh_ctx* ctx, bvh_trace_kind kind, const void* d_rays, const void
                const void* h_transform, void* d_rgba, uint32_t* d_ray_counter, uint32_t width, uint32_t height);
 /* BVH2 SAH cost with the formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349), device reduction, f64. */
 int  bvh_sah_cost(bvh_ctx* ctx, const bvh_result* in, double* cost_out);
+/* BVH4 cost with the formula of Utility::calculatebvh4Cost (src/Utility.cpp:351-396) — the value the reference's builders store in
+ * m_cost after the collapse (src/TwoPassLbvh.cpp:196, src/SinglePassLbvh.cpp:186, src/PLOC++Bvh.cpp:195, src/Hploc.cpp:164).
+ * d_bvh4 / d_primnodes / n_wide: outputs of bvh_collapse4; d_prim_aabbs: Aabb[n] by primitive index (bvh_result.d_prim_aabbs).
+ * Device reduction, f32 terms, f64 accumulation.  Blocking. */
+int  bvh_bvh4_cost(bvh_ctx* ctx, const void* d_bvh4, uint32_t n_wide, const void* d_primnodes, const void* d_prim_aabbs, uint32_t n, double* cost_out);
+/* Order-independent 64-bit checksum of a result's node array, leaf array (PLOC layouts) and root index: equal checksums <=> byte-identical
+ * results (up to hash collisions).  Lets hosts compare builds (batched vs single, run vs run) without reading the arrays back.  Blocking. */
+int  bvh_checksum(bvh_ctx* ctx, const bvh_result* in, uint64_t* checksum_out);
 /* copy a result's arrays to host (blocking), sizes per layout; any pointer may be NULL.  h_sorted_keys: u32[n] or, for
  * key_bits == 64 results, u64[n] */
 int  bvh_download(bvh_ctx* ctx, const bvh_result* in, void* h_nodes, void* h_leaves, void* h_sorted_keys,
@@ -181,6 +195,20 @@ int  bvh_download(bvh_ctx* ctx, const bvh_result* in, void* h_nodes, void* h_lea
  * E+M+S+B milliseconds per mesh.  Blocking. */
 int  bvh_batched_build(int n_dev, const int* devs, bvh_algo algo, const void* const* h_tris, const uint32_t* n_tris, int n_meshes,
                        float* root_aabbs_out, float* build_ms_out);
+/* The same as a reusable object: the per-device contexts (arenas), the RCCL communicator and the gather buffers are created once and
+ * kept across builds (bvh_batched_build pays for them on every call).  Report fields are optional except root_aabbs. */
+typedef struct bvh_batch bvh_batch;
+typedef struct {
+    float*    root_aabbs;      /* [6 * n_meshes] min xyz, max xyz per mesh, as all-gathered (device devs[0]'s copy) */
+    float*    build_ms;        /* [n_meshes] or NULL: E+M+S+B per mesh (stage events) */
+    uint64_t* checksums;       /* [n_meshes] or NULL: bvh_checksum of each mesh's tree */
+    double*   sah;             /* [n_meshes] or NULL: bvh_sah_cost of each mesh's tree */
+    float     allgather_us;    /* out: duration of the RCCL all-gather of the root boxes (HIP events, max over devices) */
+    float     wall_ms;         /* out: host wall time of the call (H2D copies of the inputs included) */
+} bvh_batch_report;
+int  bvh_batch_create(int n_dev, const int* devs, bvh_batch** out);
+int  bvh_batch_build(bvh_batch* batch, bvh_algo algo, const void* const* h_tris, const uint32_t* n_tris, int n_meshes, bvh_batch_report* report);
+void bvh_batch_destroy(bvh_batch* batch);
 
 /* wait for everything enqueued on the ctx's stream (bvh_build is asynchronous unless it has to read something back:
  * profiling on, single-pass root index, PLOC++ iteration batches) */

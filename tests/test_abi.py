@@ -34,7 +34,7 @@ def test_version_and_no_cpu_fallback(pkg):
 
 
 def test_struct_layouts(pkg):
-    assert C.sizeof(pkg.Result) == 6 * 8 + 6 * 4 and C.sizeof(pkg.BuildInput) == 2 * 4 + 3 * 8 + 2 * 4 and C.sizeof(pkg.Timings) == 6 * 4 + 2 * 4 + 8
+    assert C.sizeof(pkg.Result) == 6 * 8 + 6 * 4 + 2 * 8 and C.sizeof(pkg.BatchReport) == 4 * 8 + 2 * 4 and C.sizeof(pkg.BuildInput) == 2 * 4 + 3 * 8 + 2 * 4 and C.sizeof(pkg.Timings) == 6 * 4 + 2 * 4 + 8
     assert pkg.TRIANGLE.itemsize == 64 and pkg.BVH2_NODE.itemsize == 32 and pkg.PRIMREF.itemsize == 28 and pkg.AABB.itemsize == 24
 
 
