@@ -80,7 +80,8 @@ def test_reference_driver_runs_and_matches_ctypes_path(pkg, orc, ctx, driver, me
     R = orc.ref_utility()
     if R is not None:
         wc = np.ascontiguousarray(w); pc = np.ascontiguousarray(p)
-        assert head[2] == pytest.approx(R.ref_calculatebvh4Cost(wc.ctypes.data, pc.ctypes.data, ob.ctypes.data, 0, len(w), n - 1), rel=2e-5)
+        c_ref = R.ref_calculatebvh4Cost(wc.ctypes.data, pc.ctypes.data, ob.ctypes.data, 0, len(w), n - 1)       # f32 accumulation in node order
+        assert c_ref == pytest.approx(orc.sah_bvh4(w, p, ob, len(w), n)[1], rel=1e-6) and head[2] == pytest.approx(c_ref, rel=1e-3)
     assert head[5] > 0 and head[6] > 0 and head[7] > 0 and head[8] > 0 and head[9] > 0       # Timer tokens incl. CollapseBvhTime
     # traverseBvh's image
     if which in FLAVOUR:
