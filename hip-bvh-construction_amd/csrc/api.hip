@@ -174,7 +174,9 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
     bool fresh = true;
     // iterations needed grow by ~3 per doubling of n (measured: 30 at 262 k, 45 at 10 M); the first batch aims slightly above
     int batch = 33; for (uint32_t m = n; m > 262144u; m >>= 1) batch += 3; if (batch > 80) batch = 80; if (n < 262144u) batch = 33;
-    for (int guard = 0; guard < 4096; ++guard) {
+    // every iteration merges at least the globally closest pair, so n iterations always suffice (a collinear, zero-area scene needs
+    // almost that many: every union has area 0 and only the lowest pair of a chunk is mutual); the reference loops the same way
+    for (uint32_t guard = 0; guard < n / 16u + 4096u; ++guard) {
         if (first + batch > PLOC_MAX_ITERS) {
             // restart the per-iteration bookkeeping with the current count (pathologically slow convergence only)
             HIP_TRY(hipMemcpyAsync(host_state, sc.state, sizeof host_state, hipMemcpyDeviceToHost, c->stream));
@@ -492,16 +494,16 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[5], s));
     collapse_begin(s, taskq, state, in->root);
     u32 host[COLLAPSE_STATE_WORDS];
-    int first = 0;
-    while (first < COLLAPSE_MAX_LEVELS) {
-        const int count = (COLLAPSE_MAX_LEVELS - first) < 48 ? (COLLAPSE_MAX_LEVELS - first) : 48;
-        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, first, count, n, (int)in->layout);
+    // wide levels ~ half the BVH2 depth: a first batch sized for a balanced tree, then batches of 16 until a level creates nothing
+    int batch = 10; for (uint32_t m = n; m > 1u; m >>= 1) batch += 1;
+    bool first = true;
+    for (long long total = 0; total < (1ll << 31); total += batch, batch = 16) {
+        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, first, batch, n, (int)in->layout);
+        first = false;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host, state, sizeof host, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        first += count;
-        // done when the last processed level created nothing: allocation counter == start of the next level's snapshot
-        if (host[0] == host[1 + first]) {
+        if (host[0] == host[2]) {                      // the last processed level allocated nothing
             if (n_wide_out) *n_wide_out = host[0];
             if (c->profiling) {   // token CollapseBvhTime (src/TwoPassLbvh.cpp:182), including this implementation's level read-backs
                 HIP_TRY(hipEventRecord(c->ev[6], s)); HIP_TRY(hipEventSynchronize(c->ev[6]));

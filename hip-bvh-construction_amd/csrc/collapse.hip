@@ -10,7 +10,11 @@
 // The reference runs ONE launch in which every thread spins until its task appears (hangs unless all workgroups are
 // co-resident).  Here the wide tree is produced level by level: launch k processes the wide nodes
 // created by launch k-1 (a tiny snapshot kernel publishes the level bounds), ids are allocated with one block-aggregated
-// atomic per workgroup.  Numbering is allocation order (schedule dependent, as in the reference).
+// atomic per workgroup.  Numbering is allocation order (schedule dependent, as in the reference).  The host enqueues batches of
+// levels and reads the bounds back after each batch until a level created nothing: any depth works (a degenerate 1 M-leaf chain
+// just takes more batches).  A one-launch variant (waves taking 64-task batches from a ticket and polling their queue words) was
+// measured slower: 0.56 vs 0.30 ms at 262 k, 1.5 vs 1.2 ms at 10 M — a batch completes at the pace of its slowest task
+// (tools/probes/collapse_persistent_queue.hip.txt).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -22,16 +26,17 @@ static_assert(sizeof(Wide4) == 128 && sizeof(PrimNodeRec) == 8, "reference layou
 
 constexpr int CL_BLOCK = 256;
 
-// state: [0] allocation counter (next free wide id), [1 + k] first wide id of level k
+// state: [0] allocation counter (next free wide id), [1] / [2] first wide id of the current / the next level, [3] levels that had work
 __global__ void k_collapse_init(uint2* taskq, u32* state, u32 root) {
-    if (threadIdx.x == 0) { taskq[0] = make_uint2(root, INV); state[0] = 1; state[1] = 0; state[2] = 1; }   // src/TwoPassLbvh.cpp:160-167
+    if (threadIdx.x == 0) { taskq[0] = make_uint2(root, INV); state[0] = 1; state[1] = 0; state[2] = 1; state[3] = 0; }   // src/TwoPassLbvh.cpp:160-167
 }
-__global__ void k_collapse_snapshot(u32* state, int level) { if (threadIdx.x == 0) state[1 + level + 1] = state[0]; }
+// between two levels: the wide nodes the last level allocated are the next level
+__global__ void k_collapse_snapshot(u32* state) { if (threadIdx.x == 0) { if (state[2] > state[1]) state[3] += 1; state[1] = state[2]; state[2] = state[0]; } }
 
 __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __restrict__ nodes, const bvh_primref* __restrict__ leaves,
                                                              Wide4* __restrict__ wide, PrimNodeRec* __restrict__ prims, uint2* taskq,
-                                                             u32* state, int level, u32 n, int layout) {
-    const u32 begin = state[1 + level], end = state[1 + level + 1];
+                                                             u32* state, u32 n, int layout) {
+    const u32 begin = state[1], end = state[2];
     const u32 ni = n - 1;
     __shared__ u32 s_base, s_count;
     auto box_of = [&](u32 c) -> Box { return (layout == 1 && c >= ni) ? box_load_u(&leaves[c - ni].aabb) : box_load(&nodes[c].aabb); };
@@ -98,15 +103,15 @@ __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __
 void collapse_begin(hipStream_t s, uint2* d_taskq, u32* d_state, u32 root) {
     hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(64), 0, s, d_taskq, d_state, root);
 }
-// enqueue levels [first, first + count)
+// enqueue `count` more levels (a level without work returns at once); `first`: the very first level follows collapse_begin directly
 void collapse_enqueue(hipStream_t s, const void* d_nodes, const void* d_leaves, void* d_wide, void* d_prims, uint2* d_taskq,
-                      u32* d_state, int first, int count, u32 n, int layout) {
+                      u32* d_state, bool first, int count, u32 n, int layout) {
     u32 grid = (n / 2 + CL_BLOCK - 1) / CL_BLOCK; if (grid > 2048u) grid = 2048u; if (grid == 0) grid = 1;
     KernelScope ks(s, "k_collapse_level");
-    for (int level = first; level < first + count; ++level) {
-        if (level > 0) hipLaunchKernelGGL(k_collapse_snapshot, dim3(1), dim3(64), 0, s, d_state, level);
+    for (int level = 0; level < count; ++level) {
+        if (!(first && level == 0)) hipLaunchKernelGGL(k_collapse_snapshot, dim3(1), dim3(64), 0, s, d_state);
         hipLaunchKernelGGL(k_collapse_level, dim3(grid), dim3(CL_BLOCK), 0, s, (const bvh2_node*)d_nodes, (const bvh_primref*)d_leaves,
-                           (Wide4*)d_wide, (PrimNodeRec*)d_prims, d_taskq, d_state, level, n, layout);
+                           (Wide4*)d_wide, (PrimNodeRec*)d_prims, d_taskq, d_state, n, layout);
     }
 }
 

@@ -124,6 +124,33 @@ def test_small_arena_block_schedulers(pkg, orc, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("algo", [1, 2, 3])
+def test_collapse_has_no_depth_limit(pkg, orc, ctx, algo):
+    """round 1's collapse gave up (BVH_E_INTERNAL) after 192 wide levels; the level loop now runs until a level creates nothing.  A 1 M
+    "staircase" (geometric spacing along a line: long skewed chains) and nested shells (every triangle encloses the previous one: the
+    agglomerative builders produce a chain as deep as the mesh is long) through every builder, collapse checked against the oracle's."""
+    mg = pkg.meshgen
+    stair = mg.uniform(1_000_000, 9)
+    x = (np.float32(2.0) ** (-(np.arange(len(stair)) % 120).astype(np.float32) / 4)) + (np.arange(len(stair)) // 120).astype(np.float32) * np.float32(1e-6)
+    for v in ("v1", "v2", "v3"):
+        stair[v][:, 0] = x; stair[v][:, 1] = 0.0; stair[v][:, 2] = 0.0
+    m = 3000
+    shells = mg.uniform(m, 4)
+    r = (1.0 + np.arange(m, dtype=np.float32))
+    shells["v1"] = np.stack([-r, -r, -r], 1); shells["v2"] = np.stack([r, -r, r], 1); shells["v3"] = np.stack([-r, r, r], 1)
+    for tris in (np.ascontiguousarray(stair), np.ascontiguousarray(shells)):
+        if algo == 2:
+            tris = tris[:60_000]        # PLOC++ on a collinear zero-area scene merges ~one pair per iteration (the reference too): keep it short
+        n = len(tris)
+        b = pkg.BUILDERS[algo]().build(ctx, tris); got = b.download()
+        wide, prims, total = b.collapse4()
+        ow, opn, ototal = orc.collapse4(got["nodes"], got["leaves"], got["root"], n, got["layout"])
+        assert total == ototal and orc.topology_hash4(wide, prims, total, n) == orc.topology_hash4(ow, opn, ototal, n)
+        assert np.array_equal(np.sort(prims["prim"]), np.arange(n, dtype=np.uint32))
+        depth = orc.depth_bvh4(wide, total) if hasattr(orc, "depth_bvh4") else None
+        print(f"\n{pkg.ALGO_NAMES[algo]} n={n}: {total} wide nodes" + (f", depth {depth}" if depth else ""))
+
+
 def test_config4_image_at_sponza_262k(pkg, orc, ctx):
     """BASELINE.json configs[3] at its stated size: PLOC++ on the 262 144-triangle Sponza-class mesh -> LBVH-layout adapter -> while-while
     traversal, 512 x 512 image pixel-exact against the oracle's traversal of the oracle's tree.  Both use a 64-entry stack (the reference
