@@ -283,6 +283,29 @@ def ref_utility():
     return _ref
 
 
+# ---- the reference's PLOC++ kernels under the CPU SIMT emulator (tools/oracle/ploc_emulator.cpp -> oracle/_ref/libref_ploc_emu.so) ----
+REF_PLOC_EMU = os.path.join(_HERE, "_ref", "libref_ploc_emu.so")
+_emu = None
+
+
+def ref_emu_ploc(boxes, svals):
+    """SetupClusters + Ploc / SinglePassPloc of the reference (src/Ploc++Kernel.h) driven by its host loop (src/PLOC++Bvh.cpp:82-152),
+    executed on the CPU.  -> (nodes, leaves, iterations) or None when the library is not built (needs /root/reference)."""
+    global _emu
+    if not os.path.exists(REF_PLOC_EMU):
+        return None
+    if _emu is None:
+        _emu = C.CDLL(REF_PLOC_EMU)
+        _emu.ref_emu_ploc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    n = boxes.shape[0]
+    boxes = np.ascontiguousarray(boxes); svals = np.ascontiguousarray(svals, dtype=np.uint32)
+    nodes = np.zeros(n - 1, dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); it = C.c_uint32()
+    rc = _emu.ref_emu_ploc(boxes.ctypes.data, svals.ctypes.data, n, nodes.ctypes.data, leaves.ctypes.data, C.byref(it))
+    if rc != 0:
+        raise RuntimeError(f"ref_emu_ploc failed: {rc}")
+    return nodes, leaves, int(it.value)
+
+
 # ---- the reference's own device kernels on the GPU (oracle/_ref/*.co driven by oracle/ref_driver.cpp), when built ------
 _drv = {}
 

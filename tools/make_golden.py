@@ -9,6 +9,11 @@
       Morton keys and of the LBVH node arrays, single-pass root index, HPLOC canonical topology hash / SAH (kernel built
       with FP contraction off), plus the reference's Utility::calculateLbvhCost of its own LBVH tree.
       Copy the JSON to tests/golden/reference_outputs.json.
+  step 3 (dev container, needs /root/reference):  python tools/make_golden.py ploc
+      Outputs of the REFERENCE's PLOC++ kernels (SetupClusters, Ploc, SinglePassPloc) executed under the CPU SIMT emulator
+      (tools/oracle/ploc_emulator.cpp, built by oracle/Makefile into oracle/_ref/libref_ploc_emu.so) on the golden meshes and three larger
+      ones: FNV-1a of the node array, canonical topology hash, SAH, host-loop iterations — merged into reference_outputs.json under
+      "_ploc_emulated".  The reference's Ploc kernel cannot run on wave64 hardware, so this is its only executable form here.
 Fixtures are data (inputs and expected outputs); no reference source text is stored.
 """
 import json
@@ -32,6 +37,39 @@ def golden_meshes(pkg):
     out["probe5000"] = mg.np_mt_mesh(5000)
     out["a4_probe5000"] = mg.probe_mesh(5000)        # SURVEY.md Appendix A.4 (std::mt19937(1234))
     return out
+
+
+def ploc_meshes(pkg):
+    mg = pkg.meshgen
+    out = dict(golden_meshes(pkg))
+    out["a4_probe50000"] = mg.probe_mesh(50000)            # 105.958 / 18 iterations
+    out["sponza40000_s3"] = mg.sponza_like(40000, 3)
+    out["bunny30000_s2"] = mg.bunny_like(30000, 2)
+    return out
+
+
+def make_ploc():
+    import bvh_pkg
+    import oracle as orc
+    pkg = bvh_pkg.load()
+    path = os.path.join(GOLDEN, "reference_outputs.json")
+    res = json.load(open(path))
+    emu = {}
+    for name, tris in ploc_meshes(pkg).items():
+        n = len(tris)
+        boxes, scene = orc.prim_bounds(tris)
+        keys, _ = orc.morton_codes(boxes, scene)
+        order = np.argsort(keys, kind="stable").astype(np.uint32)
+        r = orc.ref_emu_ploc(boxes, order)
+        if r is None:
+            raise SystemExit("oracle/_ref/libref_ploc_emu.so missing: run make -C oracle ref in the dev container")
+        nodes, leaves, iters = r
+        assert orc.validate_bvh2(nodes, leaves, 0, n, 1) == 0
+        emu[name] = {"n": n, "ploc_iterations": iters, "ploc_nodes_fnv": "%016x" % orc.fnv1a(nodes), "ploc_leaves_fnv": "%016x" % orc.fnv1a(leaves),
+                     "ploc_topology": "%016x" % orc.topology_hash(nodes, leaves, 0, n, 1), "ploc_sah_f64": orc.sah_bvh2(nodes, leaves, 0, n, 1)[0]}
+        print(name, emu[name])
+    res["_ploc_emulated"] = emu
+    json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 
 
 def make_meshes():
@@ -85,6 +123,8 @@ def make_reference(out_path):
 if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "meshes":
         make_meshes()
+    elif len(sys.argv) >= 2 and sys.argv[1] == "ploc":
+        make_ploc()
     elif len(sys.argv) >= 3 and sys.argv[1] == "reference":
         make_reference(sys.argv[2])
     else:
