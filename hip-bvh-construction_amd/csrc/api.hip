@@ -98,7 +98,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->scene = k.take<float>(8);
     c->keys = reinterpret_cast<u32*>(k.take<u64>(n)); c->skeys = reinterpret_cast<u32*>(k.take<u64>(n)); c->svals = k.take<u32>(n);
     c->sort.pairs0 = k.take<uint4>(n); c->sort.pairs1 = k.take<uint4>(n);
-    c->sort.hist = k.take<u32>(SORT_MAX_PASSES * SORT_RADIX);
+    c->sort.hist = k.take<u32>(SORT_HIST_COPIES * SORT_HIST_STRIDE);
     c->sort.status = k.take<u32>(sort_status_bytes(cap) / sizeof(u32));
     c->sort.counters = k.take<u32>(SORT_MAX_PASSES);
     c->nodes = k.take<bvh2_node>(2 * n);

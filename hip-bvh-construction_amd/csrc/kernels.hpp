@@ -43,10 +43,15 @@ constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgr
 constexpr int SORT_IPT_WIDE = 20;                            // keys per thread for large inputs
 constexpr uint32_t SORT_WIDE_MIN_N = 1000000;
 constexpr int SORT_MAX_PASSES = 8;                          // 8 digits: 64-bit keys
+// The digit histograms exist in SORT_HIST_COPIES copies (copy c at hist + c * SORT_HIST_STRIDE): a producer workgroup flushes its counts
+// into copy blockIdx % copies, a sort tile adds the copies up.  One address takes ~90 atomics/us on this chip: 2048 workgroups flushing
+// into ONE copy spent 23 us queueing on every bin (k_morton 88 us at 10 M, of which the stream is 45); with 16 copies it is 1.5 us.
+constexpr int SORT_HIST_COPIES = 16;
+constexpr int SORT_HIST_STRIDE = SORT_MAX_PASSES * (1 << SORT_BITS);
 struct SortScratch {
     void*     pairs0;        // interleaved {key,value} records of the intermediate passes, ping (8 B x n for u32 keys, 16 B x n for u64)
     void*     pairs1;        // pong
-    uint32_t* hist;          // u32[SORT_MAX_PASSES * SORT_RADIX]   (zeroed by sort_prepare)
+    uint32_t* hist;          // u32[SORT_HIST_COPIES * SORT_HIST_STRIDE]: per copy, per pass, per digit (zeroed by sort_prepare)
     uint32_t* status;        // u32[SORT_MAX_PASSES * tiles * SORT_RADIX] (zeroed by sort_prepare)
     uint32_t* counters;      // u32[SORT_MAX_PASSES]                 (zeroed by sort_prepare)
 };

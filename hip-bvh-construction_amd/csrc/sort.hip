@@ -58,7 +58,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&hist[i], c); }
+    u32* copy = hist + (blockIdx.x % SORT_HIST_COPIES) * SORT_HIST_STRIDE;
+    for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&copy[i], c); }
 }
 
 // IN_AOS / OUT_AOS: the pair arrays of the intermediate passes are interleaved {key, value} u64 words — a tile's run for one
@@ -91,7 +92,15 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #define SORT_STAMP() do { } while (0)
 #endif
     SORT_STAMP();                                    // 0: start
+    // (the ticket is a returning atomic on one word, ~90 per us: the ~1000 workgroups that start together queue up to 11 us for it.  Static
+    // tile ids — BVH_SORT_DEBUG=4 in the ablation build — run four passes at 10 M in 0.257 instead of 0.297 ms, but only a ticket makes
+    // "a tile waits for running tiles only" independent of the dispatch order; sharing one ticket among the 3-4 tiles of a 1024-thread
+    // workgroup couples their barriers and is slower: 0.302 ms)
+#ifdef BVH_ABLATION
+    if (tid == 0) s_tile = (dbg & 4) ? blockIdx.x : atomicAdd(tile_counter, 1u);
+#else
     if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+#endif
 #pragma unroll
     for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
     __syncthreads();
@@ -157,7 +166,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     // raw global digit counts -> gexcl (every tile redoes that 256-entry scan from L2: cheaper than a kernel launch per sort)
     u32 gexcl;
     {
-        const u32 graw = ghist[tid];
+        u32 graw = 0;
+#pragma unroll
+        for (int c = 0; c < SORT_HIST_COPIES; ++c) graw += ghist[c * SORT_HIST_STRIDE + tid];      // (independent loads, L2 hits)
         u64 inc = ((u64)graw << 32) | total;
 #pragma unroll
         for (int off = 1; off < WAVE; off <<= 1) { const u64 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void k_prepare(u32* __restrict__ hist, u32 his
 }
 
 void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes, float* d_scene_reset, uint32_t* d_extra, uint32_t extra_words) {
-    const u32 hist_words = (u32)passes * SORT_RADIX;
+    const u32 hist_words = (u32)SORT_HIST_COPIES * SORT_HIST_STRIDE; (void)passes;
     const size_t status_words = (size_t)passes * sort_tiles(n) * SORT_RADIX;          // a multiple of 4 (SORT_RADIX = 256), 16-byte aligned base
     const u32 vecs = (u32)(status_words / 4);
     u32 blocks = (vecs + 255u) / 256u; if (blocks < 8u) blocks = 8u; if (blocks > 2048u) blocks = 2048u;

@@ -13,3 +13,11 @@ keys = np.random.default_rng(1).integers(0, 1 << 30, n, dtype=np.uint32)
 d_k = ctx.upload(keys); d_sk = ctx.alloc(n * 4); d_sv = ctx.alloc(n * 4)
 for _ in range(10): assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_sk.ptr, d_sv.ptr, 0, 30) == 0
 ctx.synchronize()
+reps = 30
+ctx.set_profiling(2)
+import time
+t0 = time.perf_counter()
+for _ in range(reps): assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_sk.ptr, d_sv.ptr, 0, 30) == 0
+ctx.synchronize(); dt = time.perf_counter() - t0
+kt = ctx.kernel_times()
+print(f"n={n} dbg={os.environ.get('BVH_SORT_DEBUG', '0')}: " + "  ".join(f"{k} {v[0] / reps:.4f} ms ({v[1] // reps} launches)" for k, v in kt.items()) + f"  wall {dt / reps * 1e3:.4f} ms", flush=True)
