@@ -62,7 +62,7 @@ EXPORTS = [
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_build_ex", "bvh_stage_extents", "bvh_stage_extents_ex",
     "bvh_stage_morton", "bvh_stage_morton64", "bvh_sort_pairs", "bvh_sort_pairs64",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_trace", "bvh_sah_cost",
-    "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_destroy",
+    "bvh_ctx_set_kernel_filter", "bvh_ctx_set_kernel_sampling", "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_destroy",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
 
@@ -154,6 +154,8 @@ def lib() -> C.CDLL:
         "bvh_bvh4_cost": ([vp, vp, u32, vp, vp, u32, C.POINTER(C.c_double)], i32),
         "bvh_checksum": ([vp, C.POINTER(Result), C.POINTER(u64)], i32),
         "bvh_ctx_last_collapse_ms": ([vp, C.POINTER(C.c_float)], i32),
+        "bvh_ctx_set_kernel_filter": ([vp, C.c_char_p], i32),
+        "bvh_ctx_set_kernel_sampling": ([vp, u32], i32),
         "bvh_batch_create": ([i32, C.POINTER(i32), C.POINTER(vp)], i32),
         "bvh_batch_build": ([vp, i32, C.POINTER(vp), C.POINTER(u32), i32, C.POINTER(BatchReport)], i32),
         "bvh_batch_destroy": ([vp], None),
@@ -231,6 +233,14 @@ class Context:
     def set_profiling(self, level) -> None:
         """0 off, 1 stage events (reference Timer tokens), 2 + per-kernel events"""
         _check(lib().bvh_ctx_set_profiling(self.handle, int(level)), "bvh_ctx_set_profiling")
+
+    def set_kernel_filter(self, name) -> None:
+        """with set_profiling(2): events for this kernel only (None: all kernels)"""
+        _check(lib().bvh_ctx_set_kernel_filter(self.handle, name.encode() if name else None), "bvh_ctx_set_kernel_filter")
+
+    def set_kernel_sampling(self, every: int) -> None:
+        """with set_profiling(2): per-kernel events for every `every`-th build only"""
+        _check(lib().bvh_ctx_set_kernel_sampling(self.handle, int(every)), "bvh_ctx_set_kernel_sampling")
 
     def kernel_times(self) -> dict:
         """{kernel name: (summed ms, launches)} since set_profiling(2)"""

@@ -20,11 +20,19 @@ namespace bvh { thread_local KernelRecorder* g_recorder = nullptr; }
 struct EventRecorder : KernelRecorder {
     struct Rec { const char* name; hipEvent_t ev; };
     std::vector<Rec> recs; size_t used = 0;
+    std::string only;                 // non-empty: record this kernel's marks only (and the mark that closes each of its intervals)
+    bool open = false;
     void mark(hipStream_t s, const char* name) override {
+        if (!only.empty()) {
+            const bool match = name && only == name;
+            if (!match && !open) return;          // an event costs ~5 us of launch gap: a build is 7 launches
+            if (!match) name = nullptr;           // closes the interval of the watched kernel
+            open = match;
+        }
         if (used == recs.size()) { Rec r{name, nullptr}; if (hipEventCreate(&r.ev) != hipSuccess) return; recs.push_back(r); }
         recs[used].name = name; (void)hipEventRecord(recs[used].ev, s); ++used;
     }
-    void reset() { used = 0; }
+    void reset() { used = 0; open = false; }
     ~EventRecorder() override { for (auto& r : recs) if (r.ev) (void)hipEventDestroy(r.ev); }
 };
 
@@ -34,6 +42,7 @@ struct bvh_ctx {
     bool own_stream = false;
     bool profiling = false;           // stage-level events (the reference's Timer tokens)
     bool kernel_profiling = false;    // + one event pair per kernel launch
+    uint32_t sample_every = 1, build_counter = 0;   // ... of every sample_every-th build only
     EventRecorder recorder;
     uint32_t cap = 0;                 // primitives the arena is sized for
     char* arena = nullptr;
@@ -287,6 +296,16 @@ int bvh_ctx_kernel_times(bvh_ctx* c, char* names_out, uint32_t names_cap, float*
     return (int)k;
 }
 int bvh_ctx_last_collapse_ms(const bvh_ctx* c, float* ms_out) { if (!c || !ms_out) return BVH_E_INVALID_ARG; *ms_out = c->last_collapse_ms; return 0; }
+int bvh_ctx_set_kernel_filter(bvh_ctx* c, const char* kernel_name) {
+    if (!c) return BVH_E_INVALID_ARG;
+    c->recorder.only = kernel_name ? kernel_name : ""; c->recorder.reset();
+    return 0;
+}
+int bvh_ctx_set_kernel_sampling(bvh_ctx* c, uint32_t every) {
+    if (!c || every == 0) return BVH_E_INVALID_ARG;
+    c->sample_every = every; c->build_counter = 0; c->recorder.reset();
+    return 0;
+}
 int bvh_ctx_synchronize(bvh_ctx* c) { if (!c) return BVH_E_INVALID_ARG; Bind b(c->device); return herr(hipStreamSynchronize(c->stream)); }
 
 int bvh_stage_extents(bvh_ctx* c, const void* d_tris, uint32_t n, void* d_prim_aabbs, void* d_scene_extent) {
@@ -385,8 +404,9 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
 static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* tm) {
     const int key_bits = in->morton_bits == 60 ? 64 : 32;
     hipStream_t s = c->stream;
-    const bool prof = c->profiling;
-    struct Install { bool on; explicit Install(bvh_ctx* c) : on(c->kernel_profiling) { if (on) g_recorder = &c->recorder; } ~Install() { if (on) g_recorder = nullptr; } } install(c);
+    const bool sampled = (c->build_counter++ % c->sample_every) == 0u;      // bvh_ctx_set_kernel_sampling: events in every n-th build only
+    const bool prof = c->profiling && sampled;
+    struct Install { bool on; explicit Install(bvh_ctx* c, bool sampled) : on(c->kernel_profiling && sampled) { if (on) g_recorder = &c->recorder; } ~Install() { if (on) g_recorder = nullptr; } } install(c, sampled);
     uint32_t ploc_iters = 0;
     int r = 0;
     if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
@@ -423,7 +443,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
                                   out->d_leaves = c->leaves; out->layout = 1; break;
     }
     r = end_emit(c); if (r) return r;
-    if (c->kernel_profiling) c->recorder.mark(s, nullptr);
+    if (install.on) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
         HIP_TRY(hipMemcpyAsync(&out->root, c->small, 4, hipMemcpyDeviceToHost, s));

@@ -62,6 +62,12 @@ typedef struct {
 int  bvh_ctx_set_profiling(bvh_ctx* ctx, int level);
 /* Per-kernel HIP-event times accumulated since the last bvh_ctx_set_profiling(ctx, 2): returns the number of distinct
  * kernels k; names_out receives k '\n'-separated names, ms_out[k] summed milliseconds, count_out[k] launch counts. */
+/* With profiling level 2, record events for ONE kernel only (its name as reported by bvh_ctx_kernel_times; NULL or "" = all kernels):
+ * two events per build instead of one per launch, so that measuring the dominant kernel inside a timed region does not stretch it. */
+int  bvh_ctx_set_kernel_filter(bvh_ctx* ctx, const char* kernel_name);
+/* With profiling level 2, record the per-kernel events of every `every`-th build only (default 1 = every build).  An event between two
+ * launches costs a few microseconds of launch gap; sampling keeps the measurement inside a timed region without stretching it. */
+int  bvh_ctx_set_kernel_sampling(bvh_ctx* ctx, uint32_t every);
 int  bvh_ctx_kernel_times(bvh_ctx* ctx, char* names_out, uint32_t names_cap, float* ms_out, uint32_t* count_out, uint32_t max_kernels);
 
 /* Result of a build.  All pointers are device pointers owned by the ctx; they stay valid until the next
