@@ -1,1 +1,4 @@
-timeout 300 python bench.py --cpu-sample 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('events(dominant only)', d['value'], d['ms_per_step'], d['kernel_ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'])"
+timeout 400 python tools/time_variants.py 10000000 2>&1 | grep -v amdgpu
+timeout 200 python tools/time_variants.py 262144 2>&1 | grep -v amdgpu | grep "padded64 30-bit"
+timeout 100 python tools/time_meshes.py 2>&1 | grep -v amdgpu | tail -8
+timeout 300 python tools/cpu_baselines.py > gpurun_out/cpu_baselines.json 2>/dev/null; cat gpurun_out/cpu_baselines.json
