@@ -65,6 +65,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 // IN_AOS / OUT_AOS: the pair arrays of the intermediate passes are interleaved {key, value} u64 words — a tile's run for one
 // digit is then 16 x 8 B = a full 128-byte line instead of two 64-byte half lines (measured: scattered SoA writes cost 36 % of a
 // pass).  The caller-facing arrays of the first and last pass stay SoA (KeyValueSoA of Oro::RadixSort::sort).
+#ifndef SORT_HELP_AFTER
+#define SORT_HELP_AFTER 4096u     // empty polls (~1.7 us each) before a thread computes an unpublished predecessor's total itself
+#endif
 #ifndef SORT_EXCHANGE_FIRST
 #define SORT_EXCHANGE_FIRST 1
 #endif
@@ -92,14 +95,18 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #define SORT_STAMP() do { } while (0)
 #endif
     SORT_STAMP();                                    // 0: start
-    // (the ticket is a returning atomic on one word, ~90 per us: the ~1000 workgroups that start together queue up to 11 us for it.  Static
-    // tile ids — BVH_SORT_DEBUG=4 in the ablation build — run four passes at 10 M in 0.257 instead of 0.297 ms, but only a ticket makes
-    // "a tile waits for running tiles only" independent of the dispatch order; sharing one ticket among the 3-4 tiles of a 1024-thread
-    // workgroup couples their barriers and is slower: 0.302 ms)
+    // Tile id = workgroup id.  Decoupled look-back makes a tile wait for its predecessors' totals; with static ids that is only deadlock-free
+    // if every predecessor is (or gets) resident, which HIP's dispatch order does not promise.  The usual cure — tile ids from an atomic
+    // ticket — costs a returning atomic on ONE word per tile (~90 per us on this chip): the ~1000 workgroups that start together queued up to
+    // 11 us for it, 10 us of every 68-us pass at 10 M.  Here progress is guaranteed differently: a thread that has polled an unpublished
+    // predecessor SORT_HELP_AFTER times counts that tile's keys for its digit itself and publishes the total on the predecessor's behalf
+    // (idempotent: the owner would write the same number), so every resident tile finishes in bounded time whatever else is scheduled.  In
+    // order dispatch never takes that path; BVH_SORT_DEBUG=8 reverses the tile order and 32 helps at the first empty poll, which is how
+    // tests/test_gpu_round2.py exercises it.
 #ifdef BVH_ABLATION
-    if (tid == 0) s_tile = (dbg & 4) ? blockIdx.x : atomicAdd(tile_counter, 1u);
+    if (tid == 0) s_tile = (dbg & 64) ? atomicAdd(tile_counter, 1u) : (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 #else
-    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+    if (tid == 0) s_tile = (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 #endif
 #pragma unroll
     for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
@@ -199,10 +206,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     // costs is that every tile keeps its CU slot until its slowest predecessor has published.
     {
         u32 excl = 0;
-        if (tile > 0 && !(dbg & 1)) {
+        if (tile > 0 && !(dbg & 1)) {      // (dbg & 1, & 2: ablation build only)
             constexpr int LB_WINDOW = 8;
             int prev = (int)tile - 1;
             bool done = false;
+            u32 stalled = 0;
+            const u32 help_after = (dbg & 32) ? 1u : SORT_HELP_AFTER;
 #ifdef BVH_ABLATION
             u32 n_steps = 0, n_empty = 0;
 #endif
@@ -224,7 +233,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #ifdef BVH_ABLATION
                 ++n_steps; if (used == 0) ++n_empty;
 #endif
-                if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
+                if (!done && used == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++stalled >= help_after) {           // predecessor `prev` may never get to run: publish its total for digit `tid` for it
+                        const u32 pb = (u32)prev * (u32)TILE, pv = min((u32)TILE, n - pb);
+                        u32 c = 0;
+                        for (u32 i = 0; i < pv; ++i) {
+                            const K k = IN_AOS ? Rec::key(reinterpret_cast<const typename Rec::type*>(keys_in)[pb + i]) : keys_in[pb + i];
+                            c += ((u32)(k >> shift) & digit_mask) == (u32)tid ? 1u : 0u;
+                        }
+                        st_agent(&status[(size_t)prev * SORT_RADIX + tid], (prev == 0 ? ST_INCL : ST_LOCAL) | c);
+                        stalled = 0;
+                    }
+                } else stalled = 0;
             }
 #ifdef BVH_ABLATION
             if ((dbg & 16) && tid == 0) { atomicAdd(tile_counter + 4, n_steps); atomicAdd(tile_counter + 8, n_empty); atomicMax(tile_counter + 12, n_steps); }
@@ -329,9 +350,9 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         hipLaunchKernelGGL(k_hist<K>, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
 #ifdef BVH_ABLATION
-    const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // measurements only: results are wrong when set
+    const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // measurements only: results are wrong when bits 1 / 2 are set
 #else
-    const int dbg = 0;
+    const int dbg = getenv("BVH_SORT_DEBUG") ? (atoi(getenv("BVH_SORT_DEBUG")) & (8 | 32)) : 0;   // test knobs of the helping path (results stay right)
 #endif
     const K* kin = keys_in; const u32* vin = vals_in;
     for (int p = 0; p < passes; ++p) {

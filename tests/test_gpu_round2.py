@@ -171,6 +171,27 @@ def test_config4_image_at_sponza_262k(pkg, orc, ctx):
     assert b.sah_cost() < pkg.SinglePassLbvh().build(ctx, tris).sah_cost()
 
 
+@pytest.mark.parametrize("knobs", [8, 32, 40])
+def test_sort_makes_progress_under_any_dispatch_order(pkg, ctx, knobs, monkeypatch):
+    """The one-sweep sort uses workgroup ids as tile ids (no ticket atomic) and stays deadlock-free because a thread that polls an unpublished
+    predecessor long enough computes that tile's digit total itself.  BVH_SORT_DEBUG=8 hands the tiles out in REVERSE order (every resident
+    tile's predecessors are not running), 32 makes threads help at the first empty poll: results must be the stable sort either way."""
+    monkeypatch.setenv("BVH_SORT_DEBUG", str(knobs))
+    L = pkg.lib()
+    for n, bits in ((1, 32), (4097, 32), (300_001, 32), (1_200_003, 30)):
+        rng = np.random.default_rng(n)
+        keys = rng.integers(0, 2**bits, n, dtype=np.uint64).astype(np.uint32); keys[::5] = keys[1 % n]
+        d_k = ctx.upload(keys); d_sk = ctx.alloc(n * 4); d_sv = ctx.alloc(n * 4)
+        assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_sk.ptr, d_sv.ptr, 0, bits) == 0
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(d_sk.download(np.uint32, n), keys[order]) and np.array_equal(d_sv.download(np.uint32, n), order.astype(np.uint32))
+    tris = pkg.meshgen.sponza_like(400_000, 3)                     # and a whole build (u64 keys: the 16-byte record path)
+    monkeypatch.delenv("BVH_SORT_DEBUG")
+    ref = pkg.HPLOC().build_ex(ctx, len(tris), tris=ctx.upload(tris), morton_bits=60).checksum()
+    monkeypatch.setenv("BVH_SORT_DEBUG", str(knobs))
+    assert pkg.HPLOC().build_ex(ctx, len(tris), tris=ctx.upload(tris), morton_bits=60).checksum() == ref
+
+
 def test_soak_slice(pkg, orc, ctx):
     """30 seconds of tools/soak.py (random sizes incl. the scheduler thresholds at 0.5 M / 1 M / 8 M, both schedulers, 30- and 60-bit keys):
     re-validates the inline-asm / relaxed-atomic hand-off protocol (csrc/common.hpp) on every driver run"""
