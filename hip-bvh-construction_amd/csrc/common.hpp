@@ -122,6 +122,23 @@ __device__ __forceinline__ void box_store(bvh_aabb* p, const Box& b) {
     f[0] = make_float2(b.lx, b.ly); f[1] = make_float2(b.lz, b.hx); f[2] = make_float2(b.hy, b.hz);
 }
 
+// ---- 16-lane DPP rows: lane l <- lane l + K of its row; lanes without a source read 0.  With two list slots per lane (slot 2l and 2l + 1) the
+// neighbour of a slot at distance r is a row shift by r / 2 (or r / 2 + 1) lanes of the other (odd r) or the same (even r) register set, so a
+// candidate union is six v_min / v_max with a DPP operand and no data movement at all.
+template <int K> __device__ __forceinline__ float row_shl(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + K, 0xF, 0xF, true));
+}
+template <int K> __device__ __forceinline__ Box row_shl(const Box& b) {
+    return { row_shl<K>(b.lx), row_shl<K>(b.ly), row_shl<K>(b.lz), row_shl<K>(b.hx), row_shl<K>(b.hy), row_shl<K>(b.hz) };
+}
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+// Aabb::area (src/Common.h:361-365) of two boxes at once (packed f32): 2 * (xy + xz + yz), same association, no contraction; x + x == 2 * x exactly
+__device__ __forceinline__ v2f_t area_pair(v2f_t lx, v2f_t ly, v2f_t lz, v2f_t hx, v2f_t hy, v2f_t hz) {
+    const v2f_t ex = hx - lx, ey = hy - ly, ez = hz - lz;
+    const v2f_t h = ex * ey + ex * ez + ey * ez;
+    return h + h;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 

@@ -39,7 +39,7 @@ constexpr u64 PS_LOCAL = 1ull << 62, PS_INCL = 2ull << 62;
 struct PlocLds {
     float lx[PL_SPAN], ly[PL_SPAN], lz[PL_SPAN], hx[PL_SPAN], hy[PL_SPAN], hz[PL_SPAN];
     u32 id[PL_SPAN];
-    u32 nn[PL_SPAN];        // nearest neighbour, as an index into the span arrays
+    u64 nn[PL_SPAN];        // nearest neighbour key {area bits, index into the span arrays}; the index is the low word
     u32 wsum[1024 / WAVE];
     u32 bcast[4];
 };
@@ -93,8 +93,11 @@ __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
 // counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
 // FIRST: the build's first iteration reads the clusters straight from the sorted values and the primitive boxes and writes the
 // PrimRef leaves on the way — SetupClusters (:39-55) fused: the initial cluster list (32 B written + 32 B read per primitive) never exists.
+#ifndef PLOC_OCC
+#define PLOC_OCC 5
+#endif
 template <int PL_BLOCK, bool FIRST>
-__global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
+__global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
                                                         bvh2_node* __restrict__ nodes,
                                                         u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
                                                         const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
         __syncthreads();
         u32 c = C;
         while (c > 1) {
-            for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = nearest(s, k, 0, (int)c);   // :131-148, range clipped to [0,c)
+            for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = (u64)nearest(s, k, 0, (int)c);   // :131-148, range clipped to [0,c)
             __syncthreads();
             // each thread owns PL_CPT consecutive list positions
             u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
@@ -133,8 +136,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
                 const int k = tid * PL_CPT + q;
                 mrg[q] = false; keep[q] = false; cid[q] = INV; pid[q] = INV; cb[q] = box_empty();
                 if (k < (int)c) {
-                    const u32 nb = s.nn[k];
-                    const bool mutual = s.nn[nb] == (u32)k;
+                    const u32 nb = (u32)s.nn[k];
+                    const bool mutual = (u32)s.nn[nb] == (u32)k;
                     mrg[q] = mutual && (u32)k < nb; keep[q] = !mutual || mrg[q];
                     cid[q] = s.id[k]; cb[q] = lds_box(s, k);
                     if (mrg[q]) { pid[q] = s.id[nb]; cb[q] = box_union(cb[q], lds_box(s, (int)nb)); }
@@ -230,13 +233,43 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
             const long long gpos = o - PL_HALO + k;
             if (gpos >= 0 && gpos < (long long)C) { u32 id; Box b; fetch((size_t)gpos, k >= PL_HALO && k < PL_HALO + PLOC_CHUNK, id, b); lds_set(s, k, id, b); }
             else s.id[k] = INV;
+            s.nn[k] = ~0ull;
         }
         __syncthreads();
         const int lo = (int)(o - PL_HALO < 0 ? PL_HALO - o : 0);                                   // first valid span entry
         const int hi = (int)((long long)C - (o - PL_HALO) < PL_SPAN ? (long long)C - (o - PL_HALO) : PL_SPAN);   // one past the last valid
-        // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270)
-        for (int k = PL_HALO - PL_RADIUS + tid; k < PL_HALO + PLOC_CHUNK + PL_RADIUS; k += PL_BLOCK)
-            if (k >= lo && k < hi) s.nn[k] = (PLOC_ABL == 2) ? (u32)(k ^ 1) : nearest(s, k, lo, hi);
+        // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270).  As the reference does it:
+        // every pair (s, s + r), r = 1..8, is evaluated ONCE and minimised as {area bits, other position} into both ends' words (LDS atomics).  A
+        // 16-lane DPP row holds 32 consecutive span entries, two per lane, and evaluates the pairs of its first 24 (common.hpp, row_shl): the
+        // boxes are read from LDS once (round 1 read the 16 neighbours of every entry: 192 LDS reads per cluster, the limiter of the mid-size iterations).
+        {
+            constexpr int ROWS = PL_BLOCK / 16, TILES = (PL_HALO + PLOC_CHUNK + PL_RADIUS + 23) / 24;     // pairs with s in [0, 1048)
+            static_assert(TILES % 4 == 0 || TILES <= ROWS, "whole waves per pass");
+            const int row = tid >> 4, rl = tid & 15;
+            for (int t = row; t < TILES; t += ROWS) {
+                const int sA = 24 * t + 2 * rl, sB = sA + 1;
+                const Box bA = (sA >= lo && sA < hi) ? lds_box(s, sA) : box_empty(), bB = (sB >= lo && sB < hi) ? lds_box(s, sB) : box_empty();
+                const int limA = (rl < 12 && sA >= lo) ? hi - sA : 0, limB = (rl < 12 && sB >= lo) ? hi - sB : 0;   // pair (s, s + r) exists iff r < lim
+                auto cand = [&](const Box& nA, const Box& nB, const int r) {
+                    const v2f_t lx = { fminf(nA.lx, bA.lx), fminf(nB.lx, bB.lx) }, ly = { fminf(nA.ly, bA.ly), fminf(nB.ly, bB.ly) }, lz = { fminf(nA.lz, bA.lz), fminf(nB.lz, bB.lz) };
+                    const v2f_t hx = { fmaxf(nA.hx, bA.hx), fmaxf(nB.hx, bB.hx) }, hy = { fmaxf(nA.hy, bA.hy), fmaxf(nB.hy, bB.hy) }, hz = { fmaxf(nA.hz, bA.hz), fmaxf(nB.hz, bB.hz) };
+                    const v2f_t area = area_pair(lx, ly, lz, hx, hy, hz);
+                    const unsigned long long kA = (unsigned long long)__float_as_uint(area.x) << 32, kB = (unsigned long long)__float_as_uint(area.y) << 32;
+                    if (r < limA) {
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA + r), kA | (u32)sA);
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA), kA | (u32)(sA + r));
+                    }
+                    if (r < limB) {
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB + r), kB | (u32)sB);
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB), kB | (u32)(sB + r));
+                    }
+                };
+                cand(bB, row_shl<1>(bA), 1);               cand(row_shl<1>(bA), row_shl<1>(bB), 2);
+                cand(row_shl<1>(bB), row_shl<2>(bA), 3);   cand(row_shl<2>(bA), row_shl<2>(bB), 4);
+                cand(row_shl<2>(bB), row_shl<3>(bA), 5);   cand(row_shl<3>(bA), row_shl<3>(bB), 6);
+                cand(row_shl<3>(bB), row_shl<4>(bA), 7);   cand(row_shl<4>(bA), row_shl<4>(bB), 8);
+            }
+        }
         __syncthreads();
         u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
         u32 packed = 0;
@@ -245,8 +278,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_ploc_iter(const float4* __restrict
             const int k = PL_HALO + tid * PL_CPT + q;
             mrg[q] = false; keep[q] = false; cid[q] = INV; pid[q] = INV; cb[q] = box_empty();
             if (k < hi) {                                                                            // :274 gIdx < nClusters
-                const u32 nb = s.nn[k];
-                const bool mutual = s.nn[nb] == (u32)k;                                              // :276-287
+                const u32 nb = (u32)s.nn[k];
+                const bool mutual = (u32)s.nn[nb] == (u32)k;                                         // :276-287
                 mrg[q] = mutual && (u32)k < nb; keep[q] = !mutual || mrg[q];
                 cid[q] = s.id[k]; cb[q] = lds_box(s, k);
                 if (mrg[q]) { pid[q] = s.id[nb]; cb[q] = box_union(cb[q], lds_box(s, (int)nb)); }
