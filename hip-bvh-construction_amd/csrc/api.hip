@@ -182,7 +182,8 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
     int first = 0, parity = 0;
     bool fresh = true;
     // iterations needed grow by ~3 per doubling of n (measured: 30 at 262 k, 45 at 10 M); the first batch aims slightly above
-    int batch = 33; for (uint32_t m = n; m > 262144u; m >>= 1) batch += 3; if (batch > 80) batch = 80; if (n < 262144u) batch = 33;
+    // (round 2: 30 at 262 k, 34 at 2 M, 40 at 10 M on uniform meshes — two more per doubling; a launch after the end still costs ~5 us)
+    int batch = 32; for (uint32_t m = n; m > 262144u; m >>= 1) batch += 2; if (batch > 80) batch = 80;
     // every iteration merges at least the globally closest pair, so n iterations always suffice (a collinear, zero-area scene needs
     // almost that many: every union has area 0 and only the lowest pair of a chunk is mutual); the reference loops the same way
     for (uint32_t guard = 0; guard < n / 16u + 4096u; ++guard) {
