@@ -306,6 +306,37 @@ def ref_emu_ploc(boxes, svals):
     return nodes, leaves, int(it.value)
 
 
+REF_LBVH_EMU = os.path.join(_HERE, "_ref", "libref_lbvh_emu.so")
+_emu_l = None
+
+
+def ref_emu_collapse(nodes, leaves, root, n, layout):
+    """the reference's CollapseToWide4Bvh kernel (LBVH layout: src/TwoPassLbvhKernel.h:237-336; PLOC layout: src/Ploc++Kernel.h:364-465) with its
+    host set-up, executed on the CPU with the whole grid resident.  -> (Bvh4Node[n_wide], PrimNode[n], n_wide) or None when not built."""
+    global _emu, _emu_l
+    path = REF_PLOC_EMU if layout == 1 else REF_LBVH_EMU
+    if not os.path.exists(path):
+        return None
+    wide = np.zeros(n, dtype=BVH4_NODE); prims = np.zeros(n, dtype=PRIM_NODE); nw = C.c_uint32()
+    if layout == 1:
+        if _emu is None:
+            _emu = C.CDLL(REF_PLOC_EMU)
+            _emu.ref_emu_ploc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        _emu.ref_emu_collapse_ploc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        padded = np.zeros(2 * n, dtype=BVH2_NODE); padded[: n - 1] = nodes          # the kernel reads node[leaf index].m_aabb (values unused)
+        lv = np.ascontiguousarray(leaves)
+        rc = _emu.ref_emu_collapse_ploc(padded.ctypes.data, lv.ctypes.data, root, n, wide.ctypes.data, prims.ctypes.data, C.byref(nw))
+    else:
+        if _emu_l is None:
+            _emu_l = C.CDLL(REF_LBVH_EMU)
+            _emu_l.ref_emu_collapse_lbvh.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        nd = np.ascontiguousarray(nodes)
+        rc = _emu_l.ref_emu_collapse_lbvh(nd.ctypes.data, root, n, wide.ctypes.data, prims.ctypes.data, C.byref(nw))
+    if rc != 0:
+        raise RuntimeError(f"ref_emu_collapse failed: {rc}")
+    return wide[: nw.value].copy(), prims, int(nw.value)
+
+
 # ---- the reference's own device kernels on the GPU (oracle/_ref/*.co driven by oracle/ref_driver.cpp), when built ------
 _drv = {}
 

@@ -11,9 +11,10 @@
       Copy the JSON to tests/golden/reference_outputs.json.
   step 3 (dev container, needs /root/reference):  python tools/make_golden.py ploc
       Outputs of the REFERENCE's PLOC++ kernels (SetupClusters, Ploc, SinglePassPloc) executed under the CPU SIMT emulator
-      (tools/oracle/ploc_emulator.cpp, built by oracle/Makefile into oracle/_ref/libref_ploc_emu.so) on the golden meshes and three larger
+      (tools/oracle/ref_emulator.cpp, built by oracle/Makefile into oracle/_ref/libref_ploc_emu.so) on the golden meshes and three larger
       ones: FNV-1a of the node array, canonical topology hash, SAH, host-loop iterations — merged into reference_outputs.json under
-      "_ploc_emulated".  The reference's Ploc kernel cannot run on wave64 hardware, so this is its only executable form here.
+      "_ploc_emulated"; and of its two CollapseToWide4Bvh kernels (whole grid resident; on the GPU they hang unless every workgroup is) under
+      "_collapse_emulated".  The reference's Ploc kernel cannot run on wave64 hardware, so this is its only executable form here.
 Fixtures are data (inputs and expected outputs); no reference source text is stored.
 """
 import json
@@ -69,6 +70,19 @@ def make_ploc():
                      "ploc_topology": "%016x" % orc.topology_hash(nodes, leaves, 0, n, 1), "ploc_sah_f64": orc.sah_bvh2(nodes, leaves, 0, n, 1)[0]}
         print(name, emu[name])
     res["_ploc_emulated"] = emu
+    # the reference's CollapseToWide4Bvh kernels (LBVH flavour on the single-pass tree, PLOC flavour on the PLOC++ tree) under the same emulator,
+    # whole grid resident: number of wide nodes, canonical wide topology, BVH4 cost (f64 sum of the reference formula's terms)
+    col = {}
+    for name, tris in golden_meshes(pkg).items():
+        n = len(tris); boxes, _ = orc.prim_bounds(tris)
+        entry = {"n": n}
+        for algo, tag in ((1, "lbvh_single"), (2, "ploc")):
+            t = orc.build_tree(algo, tris)
+            w, p, nw = orc.ref_emu_collapse(t["nodes"], t["leaves"], t["root"], n, t["layout"])
+            entry[tag] = {"n_wide": nw, "topology4": "%016x" % orc.topology_hash4(w, p, nw, n), "bvh4_cost_f64": orc.sah_bvh4(w, p, boxes, nw, n)[0]}
+        col[name] = entry
+        print("collapse", name, entry)
+    res["_collapse_emulated"] = col
     json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 
 
