@@ -12,7 +12,10 @@
 // path.  The oracle is pinned against (1) the reference's own Utility.cpp (validators + SAH cost)
 // built unmodified into oracle/_ref/libref_utility.so, and (2) the reference's own kernels compiled
 // unmodified by hipcc into oracle/_ref/*.co and executed on the MI355X by oracle/ref_driver.cpp —
-// tests/test_reference_kernels.py compares them with this file on the GPU box.  The radix sort
+// tests/test_reference_kernels.py compares them with this file on the GPU box — and (3) the reference's PLOC++ kernels (SetupClusters, Ploc,
+// SinglePassPloc) and both CollapseToWide4Bvh kernels executed on the CPU under the fiber SIMT emulator of tools/oracle/ref_emulator.cpp
+// (oracle/_ref/libref_ploc_emu.so, libref_lbvh_emu.so; outputs committed in tests/golden/reference_outputs.json): orc_ploc's node arrays
+// equal the emulated reference's byte for byte, orc_collapse4's wide trees its topology and cost.  The radix sort
 // (Orochi, un-vendored submodule, version unknown) has no reference-side pin: "parity unpinned" for
 // the sort boundary; the contract adopted is a stable ascending sort of the 32-bit key.
 //

@@ -283,7 +283,7 @@ def ref_utility():
     return _ref
 
 
-# ---- the reference's PLOC++ kernels under the CPU SIMT emulator (tools/oracle/ploc_emulator.cpp -> oracle/_ref/libref_ploc_emu.so) ----
+# ---- the reference's PLOC++ kernels under the CPU SIMT emulator (tools/oracle/ref_emulator.cpp -> oracle/_ref/libref_ploc_emu.so, libref_lbvh_emu.so) ----
 REF_PLOC_EMU = os.path.join(_HERE, "_ref", "libref_ploc_emu.so")
 _emu = None
 
