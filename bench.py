@@ -157,7 +157,7 @@ def main() -> None:
     if world > 1 and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
         torch.cuda.synchronize()
         assert torch.equal(gathered[6 * rank: 6 * rank + 6], root_box), "all-gather of root AABBs is inconsistent"
-    ctx.set_profiling(1)
+    ctx.set_kernel_sampling(1); ctx.set_profiling(1)
     builder.build(ctx, d_tris, on_device=True, n=n)          # one extra build with stage events (reference Timer tokens)
     stage = dict(builder.m_timer)
     sah = builder.sah_cost()

@@ -272,7 +272,7 @@ int bvh_ctx_device(const bvh_ctx* c) { return c ? c->device : -1; }
 void* bvh_ctx_stream(const bvh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int bvh_ctx_set_profiling(bvh_ctx* c, int level) {
     if (!c) return BVH_E_INVALID_ARG;
-    c->profiling = level != 0; c->kernel_profiling = level >= 2; c->recorder.reset();
+    c->profiling = level != 0; c->kernel_profiling = level >= 2; c->recorder.reset(); c->build_counter = 0;   // (the next build is a sampled one)
     return 0;
 }
 
