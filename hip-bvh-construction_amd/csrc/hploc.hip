@@ -566,6 +566,80 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
 }
 
+// One pass of k_hploc_ext.  The wave's two halves are sticky here: half h runs the task its owner lane h * 32 holds (queue items are
+// dealt to lanes 0 and 32).  What differs from climb_pass is the hand-over.  A finished range normally publishes its <= 16 survivors as
+// records, drains the stores, adds itself to the parent's dependency word with a returning atomic and — if that completed the parent —
+// loads both children's records back: four dependent memory round trips per level, ~7 us, and the external nodes are one long chain
+// (~13 levels at 10 M plus the chains along every tile boundary).  But most of the time the arriving child is the LAST contribution:
+// the sibling finished long ago (a tile-local range, or a small one) — the word then already holds count 2.  So the owner first READS
+// the word; if the count is 2, nobody else will touch the word again: the owner resets it, takes the parent's range from the sum, and the
+// half goes on with the parent keeping the survivors IN REGISTERS as one side of the parent's work list (carry) — no record stores, no
+// drain, no atomic, and only the sibling's records to load.  Otherwise the usual protocol runs unchanged.  (Whenever a node's continuation
+// passes to another wave it is through the usual protocol, whose drain also covers the node stores made since.)
+struct ExtCarry { u32 id, rep; Box b; int side; };    // a half's survivors after a task (slot = lane & 31 < 16); side (owner lane): 0 none, 1 = they are
+                                                      // the LEFT child of the half's next task, 2 = the RIGHT child
+template <typename K>
+__device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, ExtCarry& cw, const K* __restrict__ skeys,
+                                         const bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn) {
+    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
+    const bool have = __shfl((int)ready, hbase) != 0;
+    const u32 tL = (u32)__shfl((int)L, hbase), tR = (u32)__shfl((int)R, hbase), tP = (u32)__shfl((int)pc, hbase);
+    const int side = __shfl(cw.side, hbase);
+    const bool owner = ready && slot == 0;
+    // the owner looks up its parent now: the key loads fly while the task runs
+    u32 q = INV;
+    if (owner && !(L == 0u && R == ni)) q = parent_gap(L, R, ni, [&](u32 a, u32 b) { return closer(skeys, a, b); });
+
+    // work list (loadIndices :192-206): one child may be the half's own survivors of the previous pass
+    const bool is_left = slot < 16;
+    const u32 s = (u32)(slot & 15);
+    const u32 c_start = is_left ? tL : tP + 1u, c_len = is_left ? (tP - tL + 1u) : (tR - tP);
+    const int csrc = (side == 2 && !is_left) ? hbase + (int)s : lane;                 // a carried RIGHT child moves from slots 0..15 to 16..31
+    const u32 cid = (u32)__shfl((int)cw.id, csrc), crep = (u32)__shfl((int)cw.rep, csrc);
+    const Box cb = shfl_box(cw.b, csrc);
+    const bool carried = have && ((side == 1 && is_left) || (side == 2 && !is_left));
+    u32 id = INV, rep = INV;
+    Box b = box_empty();
+    if (carried) { id = cid; rep = crep; b = cb; }
+    const bool leaf = have && !carried && c_len <= HP_HALF && s < c_len;
+    if (leaf) { rep = c_start + s; id = ni + rep; b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1)); }
+    if (have && !carried && c_len > HP_HALF) rec_load_agent(recs + c_start + s, id, rep, b);
+    const u32 vb = (u32)(__ballot(id != INV) >> hbase);
+    const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
+    HpWork w; w.cnt = nl + nr; w.tL = tL; w.have = have; w.final_ = have && tL == 0 && tR == ni;
+    const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
+    const u32 ti = (u32)__shfl((int)id, src);
+    w.rep = (u32)__shfl((int)rep, src);
+    w.b = shfl_box(b, src);
+    w.id = ((u32)slot < w.cnt) ? ti : INV;
+
+    ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn);
+
+    // hand-over
+    bool fast = false; u32 nL = 0, nR = 0; u64 mine = 0;
+    if (owner && q != INV) {
+        mine = q == R ? dep_word(1u, L, 0u) : dep_word(1u, 0u, R);
+        const u64 cur = ld_agent(dep + q);
+        if ((cur >> 60) == 2ull) {                    // every other contribution is in: this one completes the node, nobody else touches the word
+            const u64 tot = cur + mine;
+            st_agent(dep + q, 0ull);
+            nL = (u32)(tot & DEP_MASK); nR = (u32)((tot >> 30) & DEP_MASK); fast = true;
+        }
+    }
+    const bool hfast = __shfl((int)fast, hbase) != 0;
+    // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated — unless they stay in registers
+    if (have && !w.final_ && !hfast && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);
+    if (owner) {
+        ready = false; cw.side = 0;
+        if (q != INV) {
+            if (fast) { cw.side = (q == R) ? 1 : 2; L = nL; R = nR; ready = true; }
+            else { drain_stores(); ready = dep_arrive(dep, q, mine, L, R); }      // the wave's node / record stores are in memory before the count moves
+            pc = q;
+        }
+    }
+    cw.id = w.id; cw.rep = w.rep; cw.b = w.b;
+}
+
 // External nodes (ranges crossing the tiles of k_hploc_block): the sub-queues hold the nodes whose dependencies were complete
 // when the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
 #ifndef HPX_OCC
@@ -593,6 +667,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         constexpr u32 NO_TICKET = 0xFFFFFFFFu;
         bool ready = false, dry = false, have_item = false;
         u32 pc = 0, L = 0, R = 0, tk = NO_TICKET, ipc = 0; u64 irg = 0;
+        ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
         while (true) {
             if (have_item && !ready) { pc = ipc; L = (u32)irg; R = (u32)(irg >> 32); ready = true; have_item = false; }
             if (tk != NO_TICKET && !have_item) {
@@ -603,17 +678,18 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
             if ((lane & 31) == 0 && !ready && !have_item && tk == NO_TICKET && !dry) tk = atomicAdd(head, 1u);
             const u64 rm = __ballot(ready);
             if (!rm) { if (__ballot(tk != NO_TICKET || have_item)) continue; break; }
-            climb_pass<false>(rm, ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE]);
+            ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE]);
         }
         return;
     }
     const u32 wsub = wid / HPQ_SUB, nwsub = nwaves / HPQ_SUB;
     for (u32 base = wsub * 2u; base < total; base += nwsub * 2u) {       // wave-uniform
         const u32 idx = base + (u32)(lane >> 5);
-        const bool ready = (lane & 31) == 0 && idx < total;
+        bool ready = (lane & 31) == 0 && idx < total;
         u32 pc = 0, L = 0, R = 0;
         if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
-        async_climb<false>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE]);
+        ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
+        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE]);
     }
 }
 
