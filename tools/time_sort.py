@@ -13,6 +13,10 @@ keys = np.random.default_rng(1).integers(0, 1 << 30, n, dtype=np.uint32)
 d_k = ctx.upload(keys); d_sk = ctx.alloc(n * 4); d_sv = ctx.alloc(n * 4)
 for _ in range(10): assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_sk.ptr, d_sv.ptr, 0, 30) == 0
 ctx.synchronize()
+if not (int(os.environ.get("BVH_SORT_DEBUG", "0")) & 3):          # (bits 1 / 2 are timing ablations with wrong results)
+    order = np.argsort(keys, kind="stable").astype(np.uint32)
+    sk = d_sk.download(np.uint32, n); sv = d_sv.download(np.uint32, n)
+    print("sorted == stable argsort:", bool(np.array_equal(sv, order) and np.array_equal(sk, keys[order])), flush=True)
 reps = 30
 ctx.set_profiling(2)
 import time
