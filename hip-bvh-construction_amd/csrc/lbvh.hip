@@ -30,7 +30,10 @@ __device__ __forceinline__ u64 slot_word(u32 node, u32 far) { return ((u64)(node
 // knows both children and the parent's full range, reads the sibling's box, and writes the parent node once (32 B).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr u32 LBQ_SUB = 64;        // sub-queues of the block kernel's hand-over (one atomic per block per launch)
-constexpr int LBVH_TILE = 512;     // leaves per tile of the block schedulers
+#ifndef LBVH_TILE_SIZE
+#define LBVH_TILE_SIZE 512
+#endif
+constexpr int LBVH_TILE = LBVH_TILE_SIZE;     // leaves per tile of the block schedulers
 
 // Node numbering.  Single pass (Apetrei, src/SinglePassLbvhKernel.h): an internal node's index is its split position.  Two pass (Karras,
 // src/TwoPassLbvhKernel.h:196-216): node i covers a range that has i at one end — equivalently (the children of a node with split s are
