@@ -288,6 +288,9 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
 
 // HIST_BITS > 0: also accumulate the per-pass digit histograms of the LSD radix sort that follows (digits of HIST_BITS
 // bits starting at bit 0, `passes` of them) — LDS histogram per block, flushed with one global atomic per non-empty bin.
+#ifndef MORTON_REVERSE
+#define MORTON_REVERSE 1
+#endif
 template <int HIST_BITS>
 __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
                                                      u32* __restrict__ keys, u32* __restrict__ vals, u32 n,
@@ -300,8 +303,15 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
     __syncthreads();
     const MortonPlan m = s_plan;
     const float lo[3] = { s_lo[0], s_lo[1], s_lo[2] }, ext[3] = { s_ext[0], s_ext[1], s_ext[2] };
-    const u32 stride = gridDim.x * EM_BLOCK;
-    for (u32 i = blockIdx.x * EM_BLOCK + threadIdx.x; i < n; i += stride) {
+    // tiles in descending order: stage E wrote the boxes in ascending order just before, so the last ones are the ones still in the caches
+    const u32 ntile = (n + EM_BLOCK - 1) / EM_BLOCK;
+    for (u32 tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+#if MORTON_REVERSE
+        const u32 i = (ntile - 1u - tile) * EM_BLOCK + threadIdx.x;
+#else
+        const u32 i = tile * EM_BLOCK + threadIdx.x;
+#endif
+        if (i >= n) continue;
         const Box b = box_load(boxes + i);
         // centre = (max + min) * 0.5f (src/Common.h:347); p = (centre - scene.min) / extent with IEEE divides (:381)
         const float p[3] = { ((b.hx + b.lx) * 0.5f - lo[0]) / ext[0], ((b.hy + b.ly) * 0.5f - lo[1]) / ext[1], ((b.hz + b.lz) * 0.5f - lo[2]) / ext[2] };
