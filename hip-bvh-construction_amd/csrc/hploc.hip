@@ -351,7 +351,7 @@ __global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__
 // writes is read before the next launch, so all its stores are plain cached stores and nothing is drained.
 // =====================================================================================================================
 constexpr u32 HPQ_SUB = 64;        // sub-queues (a single queue head would serialise one atomic per block)
-constexpr u32 HPQ_LOCAL = 32;      // ready items a block aggregates in LDS before falling back to one atomic per item
+constexpr u32 HPQ_LOCAL = 16;      // ready items a block aggregates in LDS before falling back to one atomic per item (typically 3-6; LDS: 7 blocks per CU need <= 23040 B each)
 
 __device__ __forceinline__ void queue_put(u32* q_pc, u64* q_rng, u32 q_cap, u32 sub, u32 at_in_sub, u32 pc, u32 L, u32 R) {
     const size_t at = (size_t)sub * q_cap + at_in_sub;
@@ -367,7 +367,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     constexpr int NW = NT / WAVE;
     static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
     constexpr int NLEV = KeyBits<K>::value;          // hierarchy levels = bits of the augmented key (64 / 96)
-    __shared__ K s_key[T + 2];                       // sorted keys of positions g0-1 .. g0+T
+    constexpr int KM = 18;                           // key margin: the hand-over probes up to 17 leaves beyond the tile's rims (small children of external
+    __shared__ K s_key[T + 2 * KM];                  // nodes) — with the margin in LDS none of them is a dependent global load; positions g0-KM .. g0+T+KM-1
     // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
     // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
     __shared__ unsigned short e_id[T], e_rep[T];     // id: 0x8000 | k = leaf ni + g0 + k;  k = node g0 + k;  0xFFFF = invalid
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             e_b[0][k] = b.lx; e_b[1][k] = b.ly; e_b[2][k] = b.lz; e_b[3][k] = b.hx; e_b[4][k] = b.hy; e_b[5][k] = b.hz;
         }
     }
-    for (int k = tid; k < T + 2; k += NT) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
+    for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
     if (tid < 128) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; }
     __syncthreads();
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     constexpr u32 M_EXT = 0xFFFFFFFFu;
     const int jmin = g0 ? (int)g0 - 1 : 0;
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
-    auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + 1]; };
+    auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + KM]; };
     int my_lv[PER]; u32 my_pos[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     // those children's far ends (child [L,p] is big iff leaf p-16 shares the prefix, child [p+1,R] iff leaf p+17 does);
     // a maximal local node (parent external) is listed for publication.  (s_task is dead as a task list: every thread is past
     // the level loop's last barrier.)
-    auto gkey = [&](int j) -> K { return (j >= jmin && j <= jmax) ? s_key[j - (int)g0 + 1] : skeys[j]; };
+    auto gkey = [&](int j) -> K { return (j >= (int)g0 - KM && j < (int)g0 + T + KM) ? s_key[j - (int)g0 + KM] : skeys[j]; };
     auto ready_push = [&](u32 pc, u32 L, u32 R) {
         const u32 at = atomicAdd(&s_nready, 1u);
         if (at < HPQ_LOCAL) { r_pc[at] = pc; r_L[at] = L; r_R[at] = R; }
