@@ -92,14 +92,14 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
 template <typename K, int T, bool KARRAS>
 __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                   const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
-                                                  uint4* __restrict__ queue, u32* __restrict__ queue_count, u32 q_cap, u32* root_out, u32 n) {
+                                                  uint4* __restrict__ queue, u32* root_out, u32 n) {
     __shared__ K s_key[T + 2];                       // sorted keys of positions g0-1 .. g0+T
     __shared__ u64 s_slot[T];                        // per gap: hand-off word of the first arriver (slot_word), 0 = nobody yet
     __shared__ float s_box[2][6][T];                 // per gap: the box its left / right child parked before the hand-off
     __shared__ unsigned char s_ext[T];               // per gap: the node's range leaves the tile
     __shared__ u64 s_q[T];                           // subtree roots handed to k_lbvh_ext: {node : 32 | i - g0 : 16 | j - g0 : 16}
     __shared__ unsigned short s_inv[KARRAS ? T : 1]; // Karras numbering: node index - g0 -> gap whose node carries it (0xFFFF: none in this tile)
-    __shared__ u32 s_nq, s_qbase;
+    __shared__ u32 s_nq;
     const int tid = threadIdx.x;
     const u32 ni = n - 1;
     const u32 g0 = blockIdx.x * (u32)T, g = g0 + (u32)tid;
@@ -172,29 +172,36 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
             node_store_plain(nodes + g0 + (u32)tid, (u32)ch, (u32)(ch >> 32), box_union(l, r));
         }
     }
+    // the tile's roots go to the tile's own segment of the queue (T entries; entry 0 carries the count in .w): no atomic, no round trip at the
+    // end of the workgroup (a returning atomic on a sub-queue head here was ~2 us of a ~20 us workgroup)
     const u32 nq = s_nq;
-    if (nq) {
-        if (tid == 0) s_qbase = atomicAdd(queue_count + (blockIdx.x % LBQ_SUB) * 32u, nq);
-        __syncthreads();
-        const size_t base = (size_t)(blockIdx.x % LBQ_SUB) * (size_t)q_cap + s_qbase;
-        for (u32 k = (u32)tid; k < nq; k += (u32)T) {
-            const u64 it = s_q[k];
-            queue[base + k] = make_uint4((u32)(it >> 32), g0 + (u32)((it >> 16) & 0xFFFFu), g0 + (u32)(it & 0xFFFFu), 0u);
-        }
+    uint4* seg = queue + (size_t)blockIdx.x * (size_t)T;
+    if (tid == 0 && nq == 0u) seg[0] = make_uint4(0u, 0u, 0u, 0u);
+    for (u32 k = (u32)tid; k < nq; k += (u32)T) {
+        const u64 it = s_q[k];
+        seg[k] = make_uint4((u32)(it >> 32), g0 + (u32)((it >> 16) & 0xFFFFu), g0 + (u32)(it & 0xFFFFu), k == 0u ? nq : 0u);
     }
 }
 
 // the subtree roots queued by k_lbvh_block (records written, boxes in memory) continue with the global second-arriver protocol
 template <typename K, bool KARRAS>
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ skeys, bvh2_node* nodes, u64* slots, const uint4* __restrict__ queue,
-                                                         const u32* __restrict__ queue_count, u32 cap, u32* root_out, u32 n) {
-    const u32 sub = blockIdx.y;
-    const u32 total = queue_count[sub * 32u];
-    for (u32 k = blockIdx.x * LBVH_BLOCK + threadIdx.x; k < total; k += gridDim.x * LBVH_BLOCK) {
-        const uint4 it = queue[(size_t)sub * cap + k];
-        const Box box = box_load(&nodes[it.x].aabb);                      // written by k_lbvh_block (previous launch)
-        // (handed over as "leaf": its record exists already, only its parent's side is still to be found)
-        lbvh_climb<K, KARRAS>(LbvhWalker{ it.y, it.z, it.x, 0u, 0u, box, true }, skeys, nodes, slots, root_out, n);
+                                                         u32 slot_shift, u32* root_out, u32 n) {
+    // 2^slot_shift lanes per tile segment (a tile hands over 2-3 roots on average, at most LBVH_TILE).  The climb is a chain of coherent round trips
+    // per lane and a wave runs as long as its longest lane: FEW roots per wave and many waves is what is fast — 64 roots per wave from a dense
+    // queue took 0.123 ms at 10 M; 8 / 16 / 32 lanes per tile (about 20 / 10 / 5 roots per wave): 0.088 / 0.076 / 0.084 ms (32: more threads than
+    // the chip holds), at 2 M 0.062 / 0.048 / 0.042.
+    const u32 ntiles = (n + (u32)LBVH_TILE - 1u) / (u32)LBVH_TILE;
+    const u32 lanes = 1u << slot_shift;
+    for (u32 idx = blockIdx.x * LBVH_BLOCK + threadIdx.x; idx < (ntiles << slot_shift); idx += gridDim.x * LBVH_BLOCK) {
+        const uint4* seg = queue + (size_t)(idx >> slot_shift) * (size_t)LBVH_TILE;
+        const u32 cnt = seg[0].w;
+        for (u32 k = idx & (lanes - 1u); k < cnt; k += lanes) {
+            const uint4 it = seg[k];
+            const Box box = box_load(&nodes[it.x].aabb);                  // written by k_lbvh_block (previous launch)
+            // (handed over as "leaf": its record exists already, only its parent's side is still to be found)
+            lbvh_climb<K, KARRAS>(LbvhWalker{ it.y, it.z, it.x, 0u, 0u, box, true }, skeys, nodes, slots, root_out, n);
+        }
     }
 }
 
@@ -291,14 +298,17 @@ static bool lbvh_use_tiles(uint32_t n) {
 // tile kernel + external climb; karras: emit the two-pass builder's node numbering instead of the single-pass one
 static void launch_lbvh_tiles(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n, void* d_nodes,
                               uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared, bool karras) {
-    const u32 cap = (u32)(queue_capacity / LBQ_SUB);    // per sub-queue
-    if (!heads_cleared) (void)hipMemsetAsync(d_queue_count, 0, LBQ_SUB * 32 * sizeof(u32), s);
-    const dim3 gt((n + LBVH_TILE - 1) / LBVH_TILE), bt(LBVH_TILE), ge(32, LBQ_SUB), be(LBVH_BLOCK);
+    (void)queue_capacity; (void)d_queue_count; (void)heads_cleared;   // (every tile owns a segment of the queue: no heads to clear)
+    const u32 ntiles = (n + LBVH_TILE - 1) / LBVH_TILE;
+    u32 slot_shift = 5;                                 // lanes per tile segment in k_lbvh_ext: as many as keep every thread resident (<= 400 k threads), 8..32
+    while (slot_shift > 3 && ((size_t)ntiles << slot_shift) > 400000u) --slot_shift;
+    const u32 eb = ((ntiles << slot_shift) + LBVH_BLOCK - 1) / LBVH_BLOCK;
+    const dim3 gt(ntiles), bt(LBVH_TILE), ge(eb < 4096u ? eb : 4096u), be(LBVH_BLOCK);
 #define LB_TILES(KK, KAR) do { \
         { KernelScope ks(s, "k_lbvh_block"); hipLaunchKernelGGL((k_lbvh_block<KK, LBVH_TILE, KAR>), gt, bt, 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
-                                                                (bvh2_node*)d_nodes, (uint4*)d_queue, d_queue_count, cap, d_root, n); } \
+                                                                (bvh2_node*)d_nodes, (uint4*)d_queue, d_root, n); } \
         { KernelScope ks(s, "k_lbvh_ext"); hipLaunchKernelGGL((k_lbvh_ext<KK, KAR>), ge, be, 0, s, (const KK*)d_skeys, (bvh2_node*)d_nodes, d_slots, (const uint4*)d_queue, \
-                                                              (const u32*)d_queue_count, cap, d_root, n); } } while (0)
+                                                              slot_shift, d_root, n); } } while (0)
     if (key_bits == 64) { if (karras) LB_TILES(u64, true); else LB_TILES(u64, false); }
     else                { if (karras) LB_TILES(u32, true); else LB_TILES(u32, false); }
 #undef LB_TILES
