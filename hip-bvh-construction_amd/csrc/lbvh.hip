@@ -289,7 +289,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
 // ---- launchers ---------------------------------------------------------------------------------------------------
 // key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes).  d_slots: u64[n], all-zero (kept clean by the
 // protocol).  Large inputs: tile kernel + external climb; d_queue: uint4[queue_capacity], d_queue_count: u32[64 * 32 + 1].
-constexpr uint32_t LBVH_BLOCK_MIN_N = 500000;      // below: one launch (k_lbvh_single / k_refit)
+constexpr uint32_t LBVH_BLOCK_MIN_N = 300000;      // below: one launch (k_lbvh_single / k_refit); measured crossover ~262 k (350 k: emit 0.057 vs 0.052 ms, 450 k: 0.068 vs 0.056)
 size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
 static bool lbvh_use_tiles(uint32_t n) {
     const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
