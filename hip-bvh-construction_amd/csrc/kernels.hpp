@@ -36,7 +36,7 @@ constexpr int SORT_BITS = 8;
 constexpr int SORT_RADIX = 1 << SORT_BITS;
 constexpr int SORT_BLOCK = 256;
 #ifndef BVH_SORT_IPT
-#define BVH_SORT_IPT 16
+#define BVH_SORT_IPT 12
 #endif
 constexpr int SORT_IPT = BVH_SORT_IPT;                        // keys per thread
 constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup (sizes the status rows)

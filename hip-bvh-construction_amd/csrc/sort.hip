@@ -21,7 +21,7 @@
 
 namespace bvh {
 
-static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit");
+static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit (k_onesweep: the first SORT_RADIX threads of the workgroup)");
 constexpr u32 ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 
 // interleaved {key, value} records of the intermediate passes: 8 bytes for u32 keys, 16 bytes {key, value, pad} for u64 keys
@@ -68,16 +68,23 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 #ifndef SORT_HELP_AFTER
 #define SORT_HELP_AFTER 4096u     // empty polls (~1.7 us each) before a thread computes an unpublished predecessor's total itself
 #endif
+// The large-input variant (n >= SORT_WIDE_MIN_N).  u32 keys: 512 threads x 13 keys = 6656-pair tiles, 61 KB of LDS, two workgroups = 16 waves per CU.
+// Same box, four passes of the stand-alone sort at 10 M: 256 x 20 (round 1 / early round 2) 0.266 ms, 512 x 10 (same tile, twice the waves) 0.265,
+// 512 x 12 / 13 / 14: 0.245 / 0.241 / 0.245, 512 x 16 (one workgroup per CU) 0.298, 768 x 8: 0.305, 1024 x 8: 0.272 (but 0.074 vs 0.079 at 1 M) —
+// what pays is fewer, larger tiles (fewer status rows for everybody's look-back) as long as two workgroups still fit a CU.  u64 keys keep 256 x 20 (65 KB).
+template <typename K> struct SortWide { static constexpr int NT = 512, IPT = 13; };
+template <> struct SortWide<u64> { static constexpr int NT = 256, IPT = SORT_IPT_WIDE; };
 #ifndef SORT_EXCHANGE_FIRST
 #define SORT_EXCHANGE_FIRST 1
 #endif
-template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT>
-__global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK>
+__global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
                                                          int shift, u32 digit_mask, const u32* __restrict__ ghist,
                                                          u32* status, u32* tile_counter, int dbg) {
-    constexpr int NW = SORT_BLOCK / WAVE;
-    constexpr int TILE = SORT_BLOCK * IPT;           // keys per workgroup
+    constexpr int NW = NT / WAVE, NDW = SORT_RADIX / WAVE;        // waves; waves that own digits (threads 0..255: one digit each)
+    constexpr int TILE = NT * IPT;                   // keys per workgroup
+    static_assert(NT % SORT_RADIX == 0, "digit threads are whole waves");
     __shared__ u32 s_whist[NW][SORT_RADIX];
     __shared__ u32 s_binoff[SORT_RADIX];
     __shared__ u32 s_gbase[SORT_RADIX];
@@ -108,8 +115,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #else
     if (tid == 0) s_tile = (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 #endif
+    const bool dig = tid < SORT_RADIX;               // this thread speaks for digit `tid`
+    if (dig) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
+        for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
+    }
     __syncthreads();
     const u32 tile = s_tile;
     const u32 base = tile * (u32)TILE;
@@ -160,8 +170,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     SORT_STAMP();                                    // 2: ranked
 
     // ---- digit `tid`: totals over the 4 waves, exclusive wave offsets back into s_whist, publish the tile aggregate
-    u32 total;
-    {
+    u32 total = 0;
+    if (dig) {
         u32 run = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { const u32 c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
@@ -171,21 +181,26 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     }
     // ---- exclusive scans over the 256 digits (wave scan + LDS hop), two in one: the tile's digit totals -> s_binoff, and the pass's
     // raw global digit counts -> gexcl (every tile redoes that 256-entry scan from L2: cheaper than a kernel launch per sort)
-    u32 gexcl;
+    u32 gexcl = 0;
     {
         u32 graw = 0;
+        u64 inc = 0;
+        if (dig) {                                   // (whole waves)
 #pragma unroll
-        for (int c = 0; c < SORT_HIST_COPIES; ++c) graw += ghist[c * SORT_HIST_STRIDE + tid];      // (independent loads, L2 hits)
-        u64 inc = ((u64)graw << 32) | total;
+            for (int c = 0; c < SORT_HIST_COPIES; ++c) graw += ghist[c * SORT_HIST_STRIDE + tid];  // (independent loads, L2 hits)
+            inc = ((u64)graw << 32) | total;
 #pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) { const u64 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-        if (lane == WAVE - 1) s_wsum[wave] = inc;
+            for (int off = 1; off < WAVE; off <<= 1) { const u64 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+            if (lane == WAVE - 1) s_wsum[wave] = inc;
+        }
         __syncthreads();
-        u64 wbase = 0;
+        if (dig) {
+            u64 wbase = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) if (w < wave) wbase += s_wsum[w];
-        const u64 ex = wbase + inc - (((u64)graw << 32) | total);
-        s_binoff[tid] = (u32)ex; gexcl = (u32)(ex >> 32);
+            for (int w = 0; w < NDW; ++w) if (w < wave) wbase += s_wsum[w];
+            const u64 ex = wbase + inc - (((u64)graw << 32) | total);
+            s_binoff[tid] = (u32)ex; gexcl = (u32)(ex >> 32);
+        }
     }
 #if SORT_EXCHANGE_FIRST
     // ---- tile-local sort through LDS, ahead of the look-back: it needs nothing from other tiles, and the predecessors publish meanwhile
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
     // costs is that every tile keeps its CU slot until its slowest predecessor has published.
     {
         u32 excl = 0;
-        if (tile > 0 && !(dbg & 1)) {      // (dbg & 1, & 2: ablation build only)
+        if (dig && tile > 0 && !(dbg & 1)) {      // (dbg & 1, & 2: ablation build only)
             constexpr int LB_WINDOW = 8;
             int prev = (int)tile - 1;
             bool done = false;
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #endif
             st_agent(&status[(size_t)tile * SORT_RADIX + tid], ST_INCL | (excl + total));
         }
-        s_gbase[tid] = gexcl + excl - s_binoff[tid];
+        if (dig) s_gbase[tid] = gexcl + excl - s_binoff[tid];
     }
     SORT_STAMP();                                    // 4: own look-back done
     __syncthreads();
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_onesweep(const K* __restrict__ k
 #endif
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        const u32 p = (u32)(k * SORT_BLOCK + tid);
+        const u32 p = (u32)(k * NT + tid);
         if (p < valid) {
             const K kk = s_keys[p];
             const u32 dst = (dbg & 2) ? base + p : s_gbase[(u32)(kk >> shift) & digit_mask] + p;
@@ -339,10 +354,11 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         else hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, vals_out, n);
         return;
     }
-    // keys per thread: 16, from SORT_WIDE_MIN_N on 20 (same box, 4 passes: 10 M 0.299 -> 0.280 ms, 2 M 0.114 -> 0.113, 262 k 0.064 -> 0.067:
+    // small inputs: 256 threads x 12 keys (4 passes at 262 k: 16 keys 0.057 ms, 12: 0.054, 8: 0.053, 4: 0.058); from SORT_WIDE_MIN_N on: SortWide (round 1:
+    // 256 x 20 instead of 256 x 16, same box, 4 passes: 10 M 0.299 -> 0.280 ms, 2 M 0.114 -> 0.113, 262 k 0.064 -> 0.067:
     // fewer tiles = fewer status rows for everybody's look-back, but a longer critical path per tile)
     const bool wide = n >= SORT_WIDE_MIN_N;
-    const u32 tile_keys = (u32)SORT_BLOCK * (wide ? SORT_IPT_WIDE : SORT_IPT);
+    const u32 tile_keys = wide ? (u32)SortWide<K>::NT * SortWide<K>::IPT : (u32)SORT_BLOCK * SORT_IPT;
     const u32 tiles = (n + tile_keys - 1u) / tile_keys;           // (<= sort_tiles(n): the status rows were sized and cleared for that)
     if (!hist_ready) {
         const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
@@ -367,8 +383,8 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         const u32* h = sc.hist + p * SORT_RADIX;
         u32* tc = sc.counters + p;
         KernelScope ks(s, "k_onesweep");
-        const dim3 g(tiles), b(SORT_BLOCK);
-#define SWEEP(IOTA, INA, OUTA) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_IPT_WIDE>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
+        const dim3 g(tiles), b(SORT_BLOCK), bw(SortWide<K>::NT);
+#define SWEEP(IOTA, INA, OUTA) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
                                   else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_IPT>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
         if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }
