@@ -71,9 +71,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 // The large-input variant (n >= SORT_WIDE_MIN_N).  u32 keys: 512 threads x 13 keys = 6656-pair tiles, 61 KB of LDS, two workgroups = 16 waves per CU.
 // Same box, four passes of the stand-alone sort at 10 M: 256 x 20 (round 1 / early round 2) 0.266 ms, 512 x 10 (same tile, twice the waves) 0.265,
 // 512 x 12 / 13 / 14: 0.245 / 0.241 / 0.245, 512 x 16 (one workgroup per CU) 0.298, 768 x 8: 0.305, 1024 x 8: 0.272 (but 0.074 vs 0.079 at 1 M) —
-// what pays is fewer, larger tiles (fewer status rows for everybody's look-back) as long as two workgroups still fit a CU.  u64 keys keep 256 x 20 (65 KB).
+// what pays is fewer, larger tiles (fewer status rows for everybody's look-back) as long as two workgroups still fit a CU.
 template <typename K> struct SortWide { static constexpr int NT = 512, IPT = 13; };
-template <> struct SortWide<u64> { static constexpr int NT = 256, IPT = SORT_IPT_WIDE; };
+template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };    // 5120-pair tiles, 68 KB: 8 passes at 10 M 0.656 (256 x 20) -> 0.610 ms; 512 x 8: 0.657, 512 x 12: 0.731
 #ifndef SORT_EXCHANGE_FIRST
 #define SORT_EXCHANGE_FIRST 1
 #endif

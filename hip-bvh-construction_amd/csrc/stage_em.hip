@@ -273,8 +273,10 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
     __syncthreads();
     const MortonPlan m = s_plan;
     const float lo[3] = { s_lo[0], s_lo[1], s_lo[2] }, ext[3] = { s_ext[0], s_ext[1], s_ext[2] };
-    const u32 stride = gridDim.x * EM_BLOCK;
-    for (u32 i = blockIdx.x * EM_BLOCK + threadIdx.x; i < n; i += stride) {
+    const u32 ntile = (n + EM_BLOCK - 1) / EM_BLOCK;                      // tiles in descending order, as in k_morton
+    for (u32 tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const u32 i = (ntile - 1u - tile) * EM_BLOCK + threadIdx.x;
+        if (i >= n) continue;
         const Box b = box_load(boxes + i);
         const float p[3] = { ((b.hx + b.lx) * 0.5f - lo[0]) / ext[0], ((b.hy + b.ly) * 0.5f - lo[1]) / ext[1], ((b.hz + b.lz) * 0.5f - lo[2]) / ext[2] };
         const u64 code = encode64(m, p[m.axis[0]], p[m.axis[1]], p[m.axis[2]]);
