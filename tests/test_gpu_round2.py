@@ -185,7 +185,7 @@ def test_sort_makes_progress_under_any_dispatch_order(pkg, ctx, knobs, monkeypat
         assert L.bvh_sort_pairs(ctx.handle, d_k.ptr, None, n, d_sk.ptr, d_sv.ptr, 0, bits) == 0
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(d_sk.download(np.uint32, n), keys[order]) and np.array_equal(d_sv.download(np.uint32, n), order.astype(np.uint32))
-    tris = pkg.meshgen.sponza_like(400_000, 3)                     # and a whole build (u64 keys: the 16-byte record path)
+    tris = pkg.meshgen.sponza_like(1_100_000, 3)                   # and a whole build (u64 keys: the 16-byte record path, large-input tiles)
     monkeypatch.delenv("BVH_SORT_DEBUG")
     ref = pkg.HPLOC().build_ex(ctx, len(tris), tris=ctx.upload(tris), morton_bits=60).checksum()
     monkeypatch.setenv("BVH_SORT_DEBUG", str(knobs))
@@ -193,7 +193,7 @@ def test_sort_makes_progress_under_any_dispatch_order(pkg, ctx, knobs, monkeypat
 
 
 def test_soak_slice(pkg, orc, ctx):
-    """30 seconds of tools/soak.py (random sizes incl. the scheduler thresholds at 0.5 M / 1 M / 8 M, both schedulers, 30- and 60-bit keys):
+    """30 seconds of tools/soak.py (random sizes incl. the scheduler thresholds at 0.3 M / 1 M / 8 M, both schedulers, 30- and 60-bit keys):
     re-validates the inline-asm / relaxed-atomic hand-off protocol (csrc/common.hpp) on every driver run"""
     spec = importlib.util.spec_from_file_location("soak", os.path.join(ROOT, "tools", "soak.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
