@@ -72,6 +72,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 // Same box, four passes of the stand-alone sort at 10 M: 256 x 20 (round 1 / early round 2) 0.266 ms, 512 x 10 (same tile, twice the waves) 0.265,
 // 512 x 12 / 13 / 14: 0.245 / 0.241 / 0.245, 512 x 16 (one workgroup per CU) 0.298, 768 x 8: 0.305, 1024 x 8: 0.272 (but 0.074 vs 0.079 at 1 M) —
 // what pays is fewer, larger tiles (fewer status rows for everybody's look-back) as long as two workgroups still fit a CU.
+// Inputs below SORT_WIDE_MIN_N: a pass is one generation of tiles (262 k keys = 85 tiles on 256 CUs), so what counts is a tile's latency: the same
+// 3072-pair tile on 1024 threads x 3 keys instead of 256 x 12 (four passes of the stand-alone sort, 256 x 12 -> 512 x 6 -> 1024 x 3: 50 k 0.040 -> 0.035 -> 0.034 ms,
+// 262 k 0.054 -> 0.050 -> 0.049, 900 k 0.078 -> 0.073 -> 0.072).
+constexpr int SORT_NARROW_NT = 1024, SORT_NARROW_IPT = SORT_TILE / 1024;
+static_assert(SORT_NARROW_NT * SORT_NARROW_IPT == SORT_TILE, "the status rows are sized for SORT_TILE-pair tiles");
 template <typename K> struct SortWide { static constexpr int NT = 512, IPT = 13; };
 template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };    // 5120-pair tiles, 68 KB: 8 passes at 10 M 0.656 (256 x 20) -> 0.610 ms; 512 x 8: 0.657, 512 x 12: 0.731
 #ifndef SORT_EXCHANGE_FIRST
@@ -358,7 +363,7 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
     // 256 x 20 instead of 256 x 16, same box, 4 passes: 10 M 0.299 -> 0.280 ms, 2 M 0.114 -> 0.113, 262 k 0.064 -> 0.067:
     // fewer tiles = fewer status rows for everybody's look-back, but a longer critical path per tile)
     const bool wide = n >= SORT_WIDE_MIN_N;
-    const u32 tile_keys = wide ? (u32)SortWide<K>::NT * SortWide<K>::IPT : (u32)SORT_BLOCK * SORT_IPT;
+    const u32 tile_keys = wide ? (u32)SortWide<K>::NT * SortWide<K>::IPT : (u32)SORT_NARROW_NT * SORT_NARROW_IPT;
     const u32 tiles = (n + tile_keys - 1u) / tile_keys;           // (<= sort_tiles(n): the status rows were sized and cleared for that)
     if (!hist_ready) {
         const u32 blocks = (n + SORT_BLOCK - 1) / SORT_BLOCK;
@@ -383,9 +388,9 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         const u32* h = sc.hist + p * SORT_RADIX;
         u32* tc = sc.counters + p;
         KernelScope ks(s, "k_onesweep");
-        const dim3 g(tiles), b(SORT_BLOCK), bw(SortWide<K>::NT);
+        const dim3 g(tiles), bn(SORT_NARROW_NT), bw(SortWide<K>::NT);
 #define SWEEP(IOTA, INA, OUTA) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
-                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_IPT>), g, b, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
+                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT>), g, bn, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
         if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }
         else if (last)          SWEEP(false, true, false);
