@@ -63,6 +63,7 @@ EXPORTS = [
     "bvh_stage_morton", "bvh_stage_morton64", "bvh_sort_pairs", "bvh_sort_pairs64",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_trace", "bvh_sah_cost",
     "bvh_ctx_set_kernel_filter", "bvh_ctx_set_kernel_sampling", "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_destroy",
+    "bvh_ctx_set_option", "bvh_ctx_get_option", "bvh_abi_version", "bvh_abi_struct_sizes",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
 
@@ -73,7 +74,7 @@ class BvhError(RuntimeError):
 
 class Timings(C.Structure):
     _fields_ = [("ms_extents", C.c_float), ("ms_morton", C.c_float), ("ms_sort", C.c_float), ("ms_build", C.c_float),
-                ("ms_collapse", C.c_float), ("ms_total", C.c_float), ("ploc_iterations", C.c_uint32), ("reserved", C.c_uint32),
+                ("ms_collapse", C.c_float), ("ms_total", C.c_float), ("ploc_iterations", C.c_uint32), ("sampled", C.c_uint32),
                 ("bytes_algorithmic", C.c_uint64)]
 
 
@@ -91,6 +92,11 @@ class BatchReport(C.Structure):
 
 
 TRI_PADDED64, TRI_PACKED36, TRI_INDEXED = 0, 1, 2
+ABI_VERSION = 3                      # BVH_ABI_VERSION of include/bvh_mi355x.h this binding was written against
+# bvh_option (bvh_ctx_set_option) and the names this harness accepts for the values
+OPT_HPLOC_SCHEDULER, OPT_LBVH_SCHEDULER, OPT_SORT_TEST_KNOBS, OPT_PLOC_SCHEDULER = 0, 1, 2, 3
+_OPTION_IDS = {"hploc": OPT_HPLOC_SCHEDULER, "lbvh": OPT_LBVH_SCHEDULER, "sort_knobs": OPT_SORT_TEST_KNOBS, "ploc": OPT_PLOC_SCHEDULER}
+_OPTION_VALUES = {"auto": 0, "default": 0, None: 0, "async": 1, "single": 1, "iter": 1, "block": 2, "tiles": 2, "persistent": 2}
 
 
 class BuildInput(C.Structure):
@@ -159,10 +165,17 @@ def lib() -> C.CDLL:
         "bvh_batch_create": ([i32, C.POINTER(i32), C.POINTER(vp)], i32),
         "bvh_batch_build": ([vp, i32, C.POINTER(vp), C.POINTER(u32), i32, C.POINTER(BatchReport)], i32),
         "bvh_batch_destroy": ([vp], None),
+        "bvh_ctx_set_option": ([vp, i32, C.c_int64], i32), "bvh_ctx_get_option": ([vp, i32, C.POINTER(C.c_int64)], i32),
+        "bvh_abi_version": ([], u32), "bvh_abi_struct_sizes": ([C.POINTER(u32)], None),
     }
     for name, (args, res) in sig.items():
         f = getattr(L, name)
         f.argtypes, f.restype = args, res
+    # ABI guard (include/bvh_mi355x.h BVH_ABI_VERSION): a binding written against another revision must not hand the library its structs
+    sizes = (u32 * 3)(); L.bvh_abi_struct_sizes(sizes)
+    if L.bvh_abi_version() != ABI_VERSION or tuple(sizes) != (C.sizeof(Result), C.sizeof(Timings), C.sizeof(BuildInput)):
+        raise BvhError(f"{LIB_PATH}: ABI revision {L.bvh_abi_version()} / struct sizes {tuple(sizes)} do not match this binding "
+                       f"({ABI_VERSION}, {(C.sizeof(Result), C.sizeof(Timings), C.sizeof(BuildInput))})")
     _lib = L
     return L
 
@@ -250,6 +263,35 @@ class Context:
             _check(k, "bvh_ctx_kernel_times")
         nm = names.value.decode().split("\n")
         return {nm[i]: (float(ms[i]), int(cnt[i])) for i in range(k)}
+
+    def set_option(self, option, value) -> None:
+        """bvh_ctx_set_option: option = OPT_* or "hploc" / "lbvh" / "ploc" / "sort_knobs"; value = int or "auto" / "async" / "single" / "block" ..."""
+        opt = _OPTION_IDS[option] if isinstance(option, str) else int(option)
+        val = _OPTION_VALUES[value] if (value is None or isinstance(value, str)) else int(value)
+        _check(lib().bvh_ctx_set_option(self.handle, opt, val), "bvh_ctx_set_option")
+
+    def get_option(self, option) -> int:
+        opt = _OPTION_IDS[option] if isinstance(option, str) else int(option)
+        v = C.c_int64()
+        _check(lib().bvh_ctx_get_option(self.handle, opt, C.byref(v)), "bvh_ctx_get_option")
+        return int(v.value)
+
+    def options(self, **kw):
+        """context manager: with ctx.options(hploc="block", lbvh="block"): ...  (restores the previous values)"""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.saved = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_inner, *exc):
+                for k, v in self_inner.saved.items():
+                    ctx.set_option(k, v)
+                return False
+        return _Scope()
 
     def reserve(self, n: int) -> None:
         _check(lib().bvh_ctx_reserve(self.handle, n), "bvh_ctx_reserve")

@@ -69,6 +69,7 @@ struct bvh_ctx {
     bool scratch_dirty = false;
     hipEvent_t ev[8] = {};
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
+    int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
 };
 
 namespace {
@@ -76,17 +77,17 @@ namespace {
 // HPLOC: one asynchronous launch below this size, LDS-tiled block kernel + external climb above (measured on MI355X: 1122 vs 966
 // Mtris/s at 262 k, 3005 vs 3416 at 2 M, 3848 vs 5616 at 10 M)
 constexpr uint32_t HPLOC_BLOCK_MIN_N = 1000000;
-inline bool hploc_use_block(uint32_t n) {
+inline bool hploc_use_block(const bvh_ctx* c, uint32_t n) {
     if (n <= 2 * hploc_block_tile()) return false;     // the root must cross tiles
-    const char* e = getenv("BVH_HPLOC_MODE");          // "async" / "block" override (A/B measurements, tests)
-    if (e && e[0] == 'a') return false;
-    if (e && e[0] == 'b') return true;
+    const int64_t o = c->options[BVH_OPT_HPLOC_SCHEDULER];   // 1 async / 2 tiles: the host's override (A/B measurements, tests)
+    if (o == 1) return false;
+    if (o == 2) return true;
     return n >= HPLOC_BLOCK_MIN_N;
 }
 // HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
 void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves,
                 bool heads_cleared = false) {
-    if (hploc_use_block(n)) launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc, heads_cleared);
+    if (hploc_use_block(c, n)) launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc, heads_cleared);
     else launch_hploc(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc);
 }
 
@@ -236,7 +237,26 @@ uint64_t algorithmic_bytes(bvh_algo a, uint32_t n) {
 
 extern "C" {
 
-const char* bvh_version(void) { return "bvh_mi355x 0.1 (gfx950)"; }
+const char* bvh_version(void) { return "bvh_mi355x 0.3 (gfx950)"; }
+uint32_t bvh_abi_version(void) { return BVH_ABI_VERSION; }
+void bvh_abi_struct_sizes(uint32_t out[3]) { if (out) { out[0] = (uint32_t)sizeof(bvh_result); out[1] = (uint32_t)sizeof(bvh_timings); out[2] = (uint32_t)sizeof(bvh_build_input); } }
+
+int bvh_ctx_set_option(bvh_ctx* c, bvh_option option, int64_t value) {
+    if (!c) return BVH_E_INVALID_ARG;
+    switch (option) {
+        case BVH_OPT_HPLOC_SCHEDULER: case BVH_OPT_LBVH_SCHEDULER: case BVH_OPT_PLOC_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_SORT_TEST_KNOBS: if (value & ~(int64_t)(8 | 32)) return BVH_E_INVALID_ARG; break;
+        default: return BVH_E_INVALID_ARG;
+    }
+    c->options[(int)option] = value;
+    c->sort.test_knobs = (int)c->options[BVH_OPT_SORT_TEST_KNOBS];
+    return 0;
+}
+int bvh_ctx_get_option(const bvh_ctx* c, bvh_option option, int64_t* value_out) {
+    if (!c || !value_out || (int)option < 0 || (int)option > 3) return BVH_E_INVALID_ARG;
+    *value_out = c->options[(int)option];
+    return 0;
+}
 
 int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
     if (!out) return BVH_E_INVALID_ARG;
@@ -365,7 +385,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     Bind b(c->device);
     int r = ensure_capacity(c, n); if (r) return r;
     r = begin_emit(c); if (r) return r;
-    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count);
+    launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, false, (int)c->options[BVH_OPT_LBVH_SCHEDULER]);
     r = end_emit(c); if (r) return r;
     if (root_out) { HIP_TRY(hipMemcpyAsync(root_out, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return 0;
@@ -378,7 +398,7 @@ int bvh_emit_lbvh_two(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_so
     int r = ensure_capacity(c, n); if (r) return r;
     r = begin_emit(c); if (r) return r;
     launch_lbvh_two(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->parent, c->flags, c->hploc.dep, c->small,
-                    c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count);
+                    c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, false, (int)c->options[BVH_OPT_LBVH_SCHEDULER]);
     return end_emit(c);
 }
 
@@ -434,9 +454,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;
     r = begin_emit(c); if (r) return r;
     switch (algo) {
-        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true); break;
+        case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true, (int)c->options[BVH_OPT_LBVH_SCHEDULER]); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags, c->hploc.dep, c->small,
-                                                  c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true); break;
+                                                  c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true, (int)c->options[BVH_OPT_LBVH_SCHEDULER]); break;
         case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, n);
@@ -458,6 +478,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
         std::memset(tm, 0, sizeof *tm);
         tm->bytes_algorithmic = algorithmic_bytes(algo, n);
         tm->ploc_iterations = ploc_iters;
+        tm->sampled = prof ? 1u : 0u;
         if (prof) {
             HIP_TRY(hipEventSynchronize(c->ev[4]));
             HIP_TRY(hipEventElapsedTime(&tm->ms_extents, c->ev[0], c->ev[1]));

@@ -31,6 +31,7 @@ namespace {
 int batch_reserve_slots(bvh_batch* b, int slots) {
     if (slots <= b->slots) return 0;
     const int n_dev = (int)b->devs.size();
+    b->slots = 0;                        // a failure below leaves some buffers freed: the next call must reallocate, whatever it asks for
     for (int d = 0; d < n_dev; ++d) {
         if (hipSetDevice(b->devs[d]) != hipSuccess) return BVH_E_INTERNAL;
         if (b->d_send[d]) (void)hipFree(b->d_send[d]);
@@ -109,15 +110,16 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
     rc = err.load();
     // ---- the only collective: all-gather of the root-AABB slots
     if (!rc) {
+        // RCCL enqueues the collective's kernels at ncclGroupEnd, not at the ncclAllGather call inside the group: the events that bracket it are
+        // recorded on each device's stream before the group starts and after it ended (inside the group both would precede the collective)
+        for (int d = 0; d < n_dev; ++d) { (void)hipSetDevice(b->devs[d]); (void)hipEventRecord(b->ev0[d], (hipStream_t)bvh_ctx_stream(b->ctx[d])); }
         ncclGroupStart();
         for (int d = 0; d < n_dev; ++d) {
             (void)hipSetDevice(b->devs[d]);
-            hipStream_t s = (hipStream_t)bvh_ctx_stream(b->ctx[d]);
-            (void)hipEventRecord(b->ev0[d], s);
-            if (ncclAllGather(b->d_send[d], b->d_recv[d], (size_t)slots * 6, ncclFloat, b->comms[d], s) != ncclSuccess) rc = BVH_E_INTERNAL;
-            (void)hipEventRecord(b->ev1[d], s);
+            if (ncclAllGather(b->d_send[d], b->d_recv[d], (size_t)slots * 6, ncclFloat, b->comms[d], (hipStream_t)bvh_ctx_stream(b->ctx[d])) != ncclSuccess) rc = BVH_E_INTERNAL;
         }
-        ncclGroupEnd();
+        if (ncclGroupEnd() != ncclSuccess) rc = BVH_E_INTERNAL;
+        for (int d = 0; d < n_dev; ++d) { (void)hipSetDevice(b->devs[d]); (void)hipEventRecord(b->ev1[d], (hipStream_t)bvh_ctx_stream(b->ctx[d])); }
         for (int d = 0; d < n_dev && !rc; ++d) rc = bvh_ctx_synchronize(b->ctx[d]);
         float worst = 0.f;
         for (int d = 0; d < n_dev && !rc; ++d) {

@@ -54,6 +54,7 @@ struct SortScratch {
     uint32_t* hist;          // u32[SORT_HIST_COPIES * SORT_HIST_STRIDE]: per copy, per pass, per digit (zeroed by sort_prepare)
     uint32_t* status;        // u32[SORT_MAX_PASSES * tiles * SORT_RADIX] (zeroed by sort_prepare)
     uint32_t* counters;      // u32[SORT_MAX_PASSES]                 (zeroed by sort_prepare)
+    int       test_knobs;    // BVH_OPT_SORT_TEST_KNOBS (8 | 32): forces the helping path; results unchanged
 };
 inline uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 inline int sort_passes(int start_bit, int end_bit) { return (end_bit - start_bit + SORT_BITS - 1) / SORT_BITS; }
@@ -75,12 +76,12 @@ void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in,
 size_t lbvh_queue_capacity(uint32_t n);
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, uint64_t* d_slots /*u64[n]*/, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count,
-                        bool heads_cleared = false /* d_queue_count is already zero */);
+                        bool heads_cleared = false /* d_queue_count is already zero */, int scheduler = 0 /* BVH_OPT_LBVH_SCHEDULER */);
 // small inputs: k_karras + k_refit (d_parent u32[2n-1]; d_flags u32[n], all 0xFFFFFFFF before the call and left so); large inputs: the tile
 // scheduler with the two-pass numbering (d_slots / d_root / d_queue / d_queue_count as for launch_lbvh_single)
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent /*u32[2n-1]*/, uint32_t* d_flags /*u32[n]*/, uint64_t* d_slots, uint32_t* d_root,
-                     void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared = false);
+                     void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared = false, int scheduler = 0);
 // HPLOC scratch (hploc.hip).  dep must be all-zero before a build and is left all-zero by a completed build.
 struct HplocScratch {
     void*     recs;          // 32-byte survivor records {id, rep, box} x n

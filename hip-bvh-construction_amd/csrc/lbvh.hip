@@ -291,9 +291,8 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
 // protocol).  Large inputs: tile kernel + external climb; d_queue: uint4[queue_capacity], d_queue_count: u32[64 * 32 + 1].
 constexpr uint32_t LBVH_BLOCK_MIN_N = 300000;      // below: one launch (k_lbvh_single / k_refit); measured crossover ~262 k (350 k: emit 0.057 vs 0.052 ms, 450 k: 0.068 vs 0.056)
 size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
-static bool lbvh_use_tiles(uint32_t n) {
-    const char* e = getenv("BVH_LBVH_MODE");           // "single" / "block" override (A/B measurements, tests)
-    return (e && e[0] == 'b') ? true : (e && e[0] == 's') ? false : n >= LBVH_BLOCK_MIN_N;
+static bool lbvh_use_tiles(uint32_t n, int scheduler) {   // scheduler: BVH_OPT_LBVH_SCHEDULER (1 one-launch kernels, 2 tiles: the host's override)
+    return scheduler == 2 ? true : scheduler == 1 ? false : n >= LBVH_BLOCK_MIN_N;
 }
 // tile kernel + external climb; karras: emit the two-pass builder's node numbering instead of the single-pass one
 static void launch_lbvh_tiles(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n, void* d_nodes,
@@ -315,8 +314,8 @@ static void launch_lbvh_tiles(hipStream_t s, const void* d_boxes, const void* d_
 }
 
 void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared) {
-    if (!lbvh_use_tiles(n) || !d_queue || queue_capacity < lbvh_queue_capacity(n)) {   // (a tile may queue up to T roots: never run the tile kernel on a smaller queue)
+                        void* d_nodes, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared, int scheduler) {
+    if (!lbvh_use_tiles(n, scheduler) || !d_queue || queue_capacity < lbvh_queue_capacity(n)) {   // (a tile may queue up to T roots: never run the tile kernel on a smaller queue)
         const u32 blocks = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
         KernelScope ks(s, "k_lbvh_single");
         if (key_bits == 64) hipLaunchKernelGGL(k_lbvh_single<u64>, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const u64*)d_skeys, d_svals, (bvh2_node*)d_nodes, d_slots, d_root, n);
@@ -331,8 +330,8 @@ void launch_lbvh_single(hipStream_t s, const void* d_boxes, const void* d_skeys,
 // searches, no parent array): d_slots / d_root / d_queue / d_queue_count as for launch_lbvh_single.
 void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                      void* d_nodes, uint32_t* d_parent, uint32_t* d_flags, uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity,
-                     uint32_t* d_queue_count, bool heads_cleared) {
-    if (lbvh_use_tiles(n) && d_queue && queue_capacity >= lbvh_queue_capacity(n)) {
+                     uint32_t* d_queue_count, bool heads_cleared, int scheduler) {
+    if (lbvh_use_tiles(n, scheduler) && d_queue && queue_capacity >= lbvh_queue_capacity(n)) {
         launch_lbvh_tiles(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_slots, d_root, d_queue, queue_capacity, d_queue_count, heads_cleared, true);
         return;
     }

@@ -371,9 +371,10 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         hipLaunchKernelGGL(k_hist<K>, dim3(blocks < 1024u ? blocks : 1024u), dim3(SORT_BLOCK), 0, s, keys_in, n, start_bit, end_bit, passes, sc.hist);
     }
 #ifdef BVH_ABLATION
-    const int dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // measurements only: results are wrong when bits 1 / 2 are set
+    static const int env_dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // ablation build, measurements only: results are wrong when bits 1 / 2 are set
+    const int dbg = env_dbg | (sc.test_knobs & (8 | 32));
 #else
-    const int dbg = getenv("BVH_SORT_DEBUG") ? (atoi(getenv("BVH_SORT_DEBUG")) & (8 | 32)) : 0;   // test knobs of the helping path (results stay right)
+    const int dbg = sc.test_knobs & (8 | 32);              // BVH_OPT_SORT_TEST_KNOBS: test knobs of the helping path (results stay right)
 #endif
     const K* kin = keys_in; const u32* vin = vals_in;
     for (int p = 0; p < passes; ++p) {

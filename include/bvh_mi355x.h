@@ -40,6 +40,18 @@ int  bvh_ctx_reserve(bvh_ctx* ctx, uint32_t n);
 int  bvh_ctx_device(const bvh_ctx* ctx);
 void* bvh_ctx_stream(const bvh_ctx* ctx);
 
+/* Per-context options.  The library never reads environment variables: which scheduler a builder uses is decided by the input size unless
+ * the host says otherwise here (tests and A/B measurements do).  Unknown option or value: BVH_E_INVALID_ARG, nothing changes. */
+typedef enum {
+    BVH_OPT_HPLOC_SCHEDULER = 0,   /* 0 auto (by n; default), 1 one asynchronous launch (k_hploc), 2 tile kernel + external climb (k_hploc_block / k_hploc_ext) */
+    BVH_OPT_LBVH_SCHEDULER  = 1,   /* 0 auto (by n; default), 1 one-launch kernels (k_lbvh_single / k_karras + k_refit), 2 tile scheduler (k_lbvh_block / k_lbvh_ext) */
+    BVH_OPT_SORT_TEST_KNOBS = 2,   /* bit mask, default 0; results are identical for every value.  8: tiles are handed out in reverse order; 32: threads help at
+                                      the first empty poll (both force the one-sweep sort's helping path, which in-order dispatch never takes) */
+    BVH_OPT_PLOC_SCHEDULER  = 3    /* 0 auto (default), 1 one launch per iteration, 2 persistent multi-iteration launches wherever the cluster list fits */
+} bvh_option;
+int  bvh_ctx_set_option(bvh_ctx* ctx, bvh_option option, int64_t value);
+int  bvh_ctx_get_option(const bvh_ctx* ctx, bvh_option option, int64_t* value_out);
+
 /* Builder selection = the reference's compile-time switch in src/main.cpp:18-22. */
 typedef enum {
     BVH_LBVH_TWOPASS    = 0,   /* TwoPassLbvh::build    src/TwoPassLbvh.cpp:17-197    */
@@ -54,7 +66,9 @@ typedef enum {
 typedef struct {
     float    ms_extents, ms_morton, ms_sort, ms_build, ms_collapse, ms_total;
     uint32_t ploc_iterations;          /* PLOC++: NN/merge rounds executed on device */
-    uint32_t reserved;
+    uint32_t sampled;                  /* 1: the ms_* fields of this build were recorded; 0: they are zero — profiling is off, or
+                                          bvh_ctx_set_kernel_sampling(ctx, k) made this one of the k-1 un-instrumented builds (hosts that
+                                          average ms_* over builds must skip those) */
     uint64_t bytes_algorithmic;        /* DESIGN.md "algorithmic bytes" for this build (n x per-prim figure) */
 } bvh_timings;
 /* level 0: no events (bvh_build fully asynchronous where it can be); 1: one event per stage (the reference's Timer tokens);
@@ -65,8 +79,9 @@ int  bvh_ctx_set_profiling(bvh_ctx* ctx, int level);
 /* With profiling level 2, record events for ONE kernel only (its name as reported by bvh_ctx_kernel_times; NULL or "" = all kernels):
  * two events per build instead of one per launch, so that measuring the dominant kernel inside a timed region does not stretch it. */
 int  bvh_ctx_set_kernel_filter(bvh_ctx* ctx, const char* kernel_name);
-/* With profiling level 2, record the per-kernel events of every `every`-th build only (default 1 = every build).  An event between two
- * launches costs a few microseconds of launch gap; sampling keeps the measurement inside a timed region without stretching it. */
+/* Record events (stage events of level 1 AND per-kernel events of level 2) in every `every`-th build only (default 1 = every build).  An event
+ * between two launches costs a few microseconds of launch gap and the stage times need a host wait at the end of the build; sampling keeps
+ * the measurement inside a timed region without stretching it.  The other builds return bvh_timings with sampled = 0 and all ms_* zero. */
 int  bvh_ctx_set_kernel_sampling(bvh_ctx* ctx, uint32_t every);
 int  bvh_ctx_kernel_times(bvh_ctx* ctx, char* names_out, uint32_t names_cap, float* ms_out, uint32_t* count_out, uint32_t max_kernels);
 
@@ -228,6 +243,13 @@ int  bvh_dev_download(bvh_ctx* ctx, void* h_dst, const void* d_src, uint64_t byt
 int  bvh_dev_copy(bvh_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device->device, asynchronous on the ctx's stream */
 
 const char* bvh_version(void);
+/* ABI revision of this header (BVH_ABI_VERSION): bumped whenever a struct of this file changes size or an entry point changes signature, so that a host
+ * compiled against an older header can refuse to run instead of handing the library a too-small bvh_result.  Revision 3: bvh_result carries d_tris and
+ * d_morton_keys (88 bytes; round 2 grew it without a bump), bvh_ctx_set_option / bvh_ctx_get_option exist. */
+#define BVH_ABI_VERSION 3
+uint32_t bvh_abi_version(void);
+/* sizeof(bvh_result) / sizeof(bvh_timings) / sizeof(bvh_build_input) as the LIBRARY was compiled: out[0..2] */
+void bvh_abi_struct_sizes(uint32_t out[3]);
 
 #ifdef __cplusplus
 }

@@ -49,4 +49,16 @@ def ctx(pkg):
     c.close()
 
 
+@pytest.fixture
+def sched_opts(ctx):
+    """sched_opts(hploc="block", lbvh="block", sort_knobs=8, ploc="persistent") sets bvh_ctx options on the session ctx for one test; all are reset afterwards.
+    (The library reads no environment variables: schedulers are chosen by size unless the host overrides them per context.)"""
+    def setter(**kw):
+        for k, v in kw.items():
+            ctx.set_option(k, v)
+    yield setter
+    for k in ("hploc", "lbvh", "sort_knobs", "ploc"):
+        ctx.set_option(k, 0)
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -24,6 +24,24 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.EXPORTS) == declared, "python binding table out of sync with the header"
 
 
+def test_abi_revision_and_struct_sizes(pkg):
+    """BVH_ABI_VERSION is bumped whenever a struct of the header changes size (bvh_result grew in round 2 without one): the library reports the
+    revision and the sizes it was compiled with; the binding refuses to load a mismatch (pkg.lib())"""
+    L = pkg.lib()
+    hdr = open(os.path.join(ROOT, "include", "bvh_mi355x.h")).read()
+    assert int(re.search(r"#define\s+BVH_ABI_VERSION\s+(\d+)", hdr).group(1)) == L.bvh_abi_version() == pkg.ABI_VERSION == 3
+    sizes = (C.c_uint32 * 3)(); L.bvh_abi_struct_sizes(sizes)
+    assert tuple(sizes) == (C.sizeof(pkg.Result), C.sizeof(pkg.Timings), C.sizeof(pkg.BuildInput)) == (88, 40, 40)
+    assert b"0.3" in L.bvh_version()
+
+
+def test_library_reads_no_environment(pkg):
+    """scheduler / test knobs are per-context options (bvh_ctx_set_option); the release library must not call getenv at all"""
+    import subprocess
+    r = subprocess.run(["nm", "-D", "--undefined-only", pkg.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0 and "getenv" not in r.stdout, "libbvh_mi355x.so imports getenv"
+
+
 def test_version_and_no_cpu_fallback(pkg):
     assert b"gfx950" in pkg.lib().bvh_version()
     import torch

@@ -110,11 +110,10 @@ def test_morton64_and_sort64(pkg, orc, ctx, name):
 @pytest.mark.parametrize("mode", ["async", "block"])
 @pytest.mark.parametrize("algo", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", ["uniform_3001", "sponza_70k", "dups"])
-def test_build_60bit_keys(pkg, orc, ctx, name, algo, mode, monkeypatch):
+def test_build_60bit_keys(pkg, orc, ctx, name, algo, mode, sched_opts):
     if mode == "block" and algo == 2:
         pytest.skip("scheduler choice only concerns HPLOC and the LBVH builders")
-    monkeypatch.setenv("BVH_HPLOC_MODE", mode)
-    monkeypatch.setenv("BVH_LBVH_MODE", "block" if mode == "block" else "single")
+    sched_opts(hploc=mode, lbvh="block" if mode == "block" else "single")
     tris = _dup_heavy(pkg) if name == "dups" else _meshes(pkg)[name]; n = len(tris)
     d_tris = ctx.upload(tris)
     b = pkg.BUILDERS[algo]().build_ex(ctx, n, tris=d_tris, morton_bits=60)

@@ -34,12 +34,9 @@ def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
     _, scene = orc.prim_bounds(big)
     hashes, sahs = [], []
     for mode in ("block", "async"):
-        os.environ["BVH_HPLOC_MODE"] = mode
-        try:
+        with ctx.options(hploc=mode):
             b = pkg.HPLOC().build(ctx, big)
             got = b.download()
-        finally:
-            del os.environ["BVH_HPLOC_MODE"]
         _check_common(pkg, orc, got, big, scene)
         assert np.array_equal(got["leaves"]["prim"], got["sorted_vals"])
         hashes.append(orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1))
@@ -55,11 +52,8 @@ def test_hploc_ticket_climb_on_clustered_60bit_keys(pkg, orc, ctx):
     d_tris = ctx.upload(tris)
     hashes = []
     for mode in ("block", "async"):
-        os.environ["BVH_HPLOC_MODE"] = mode
-        try:
+        with ctx.options(hploc=mode):
             got = pkg.HPLOC().build_ex(ctx, n, tris=d_tris, morton_bits=60).download()
-        finally:
-            del os.environ["BVH_HPLOC_MODE"]
         k = got["sorted_keys"]
         assert k.dtype == np.uint64 and np.all(k[1:] >= k[:-1])
         assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0

@@ -210,11 +210,10 @@ def test_stage_level_emitters(pkg, orc, ctx, cases, name):
 
 
 @pytest.mark.parametrize("mode", ["async", "block"])
-def test_every_small_size(pkg, orc, ctx, mode, monkeypatch):
+def test_every_small_size(pkg, orc, ctx, mode, sched_opts):
     """n = 2..70 and a few sizes around the 16/32/64 thresholds and the block scheduler's 512-leaf tile, all four builders, both
     HPLOC schedulers (the block scheduler needs more than two tiles and hands smaller inputs to the asynchronous one)"""
-    monkeypatch.setenv("BVH_HPLOC_MODE", mode)
-    monkeypatch.setenv("BVH_LBVH_MODE", "block" if mode == "block" else "single")     # single-pass LBVH: tile scheduler / one-launch kernel
+    sched_opts(hploc=mode, lbvh="block" if mode == "block" else "single")     # single-pass LBVH: tile scheduler / one-launch kernel
     for n in list(range(2, 71)) + [127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1026, 1535, 1536, 1537, 2047, 2048, 2049, 4097]:
         tris = pkg.meshgen.uniform(n, 1000 + n)
         for algo in ((0, 1, 2, 3) if mode == "async" else (0, 1, 3)):
@@ -229,11 +228,11 @@ def test_every_small_size(pkg, orc, ctx, mode, monkeypatch):
 @pytest.mark.parametrize("sched", ["default", "block"])
 @pytest.mark.parametrize("kind", ["identical", "two_far_clusters", "line", "point_cloud_dups", "huge_and_tiny", "staircase"])
 @pytest.mark.parametrize("algo", [0, 1, 2, 3])
-def test_degenerate_distributions(pkg, orc, ctx, kind, algo, sched, monkeypatch):
+def test_degenerate_distributions(pkg, orc, ctx, kind, algo, sched, sched_opts):
     if sched == "block":
         if algo == 2:
             pytest.skip("tile schedulers exist for the LBVH builders and HPLOC")
-        monkeypatch.setenv("BVH_HPLOC_MODE", "block"); monkeypatch.setenv("BVH_LBVH_MODE", "block")
+        sched_opts(hploc="block", lbvh="block")
     mg = pkg.meshgen
     if kind == "identical":            # every Morton key equal: the hierarchy comes from the position bits only
         tris = np.repeat(mg.uniform(1, 3), 3000)

@@ -79,10 +79,10 @@ def test_bvh4_cost_on_device(pkg, orc, ctx, algo, name, n):
 
 @pytest.mark.parametrize("mode", ["async", "block"])
 @pytest.mark.parametrize("n", [5000, 40_000])
-def test_emit_hploc_keys_spanning_bit_31(pkg, orc, ctx, n, mode, monkeypatch):
+def test_emit_hploc_keys_spanning_bit_31(pkg, orc, ctx, n, mode, sched_opts):
     """bvh_emit_hploc takes ANY sorted u32 keys (the reference compares the full 64-bit {key, index} words): keys on both sides of bit 31
     make the root gap's common prefix empty (length 0) — the case a shift by 64 - c mishandles — and must not poison the ctx's scratch"""
-    monkeypatch.setenv("BVH_HPLOC_MODE", mode)
+    sched_opts(hploc=mode)
     rng = np.random.default_rng(n)
     tris = pkg.meshgen.uniform(n, 3)
     boxes, _ = orc.prim_bounds(tris)
@@ -106,11 +106,11 @@ def test_emit_hploc_keys_spanning_bit_31(pkg, orc, ctx, n, mode, monkeypatch):
     assert orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1)
 
 
-def test_small_arena_block_schedulers(pkg, orc, monkeypatch):
+def test_small_arena_block_schedulers(pkg, orc):
     """a FRESH ctx whose arena is sized by a small build, tile schedulers forced: the tile kernels must never run on a root queue smaller
     than a tile can fill (round 1's session-wide, large-arena ctx hid that)"""
-    monkeypatch.setenv("BVH_HPLOC_MODE", "block"); monkeypatch.setenv("BVH_LBVH_MODE", "block")
     c = pkg.Context(0)
+    c.set_option("hploc", "block"); c.set_option("lbvh", "block")
     try:
         for n in (1500, 3000, 20_000):
             tris = pkg.meshgen.sponza_like(n, 9); n = len(tris)
@@ -172,11 +172,11 @@ def test_config4_image_at_sponza_262k(pkg, orc, ctx):
 
 
 @pytest.mark.parametrize("knobs", [8, 32, 40])
-def test_sort_makes_progress_under_any_dispatch_order(pkg, ctx, knobs, monkeypatch):
+def test_sort_makes_progress_under_any_dispatch_order(pkg, ctx, knobs, sched_opts):
     """The one-sweep sort uses workgroup ids as tile ids (no ticket atomic) and stays deadlock-free because a thread that polls an unpublished
-    predecessor long enough computes that tile's digit total itself.  BVH_SORT_DEBUG=8 hands the tiles out in REVERSE order (every resident
+    predecessor long enough computes that tile's digit total itself.  BVH_OPT_SORT_TEST_KNOBS = 8 hands the tiles out in REVERSE order (every resident
     tile's predecessors are not running), 32 makes threads help at the first empty poll: results must be the stable sort either way."""
-    monkeypatch.setenv("BVH_SORT_DEBUG", str(knobs))
+    sched_opts(sort_knobs=knobs)
     L = pkg.lib()
     for n, bits in ((1, 32), (4097, 32), (300_001, 32), (1_200_003, 30)):
         rng = np.random.default_rng(n)
@@ -186,9 +186,9 @@ def test_sort_makes_progress_under_any_dispatch_order(pkg, ctx, knobs, monkeypat
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(d_sk.download(np.uint32, n), keys[order]) and np.array_equal(d_sv.download(np.uint32, n), order.astype(np.uint32))
     tris = pkg.meshgen.sponza_like(1_100_000, 3)                   # and a whole build (u64 keys: the 16-byte record path, large-input tiles)
-    monkeypatch.delenv("BVH_SORT_DEBUG")
+    sched_opts(sort_knobs=0)
     ref = pkg.HPLOC().build_ex(ctx, len(tris), tris=ctx.upload(tris), morton_bits=60).checksum()
-    monkeypatch.setenv("BVH_SORT_DEBUG", str(knobs))
+    sched_opts(sort_knobs=knobs)
     assert pkg.HPLOC().build_ex(ctx, len(tris), tris=ctx.upload(tris), morton_bits=60).checksum() == ref
 
 
@@ -207,10 +207,7 @@ def test_soak_slice(pkg, orc, ctx):
         d = ctx.upload(tris)
         cks = []
         for mode in ("block", "async"):
-            os.environ["BVH_HPLOC_MODE"] = mode
-            try:
+            with ctx.options(hploc=mode):
                 cks.append(pkg.HPLOC().build_ex(ctx, n, tris=d).checksum())
-            finally:
-                del os.environ["BVH_HPLOC_MODE"]
         d.free()
         assert cks[0] == cks[1], n

@@ -20,7 +20,7 @@ pkg = bvh_pkg.load(); ctx = pkg.Context(0)
 modes = a.modes.split(",")
 
 def build(mode, tris):
-    os.environ["BVH_HPLOC_MODE"] = mode
+    ctx.set_option("hploc", mode)
     b = pkg.HPLOC().build(ctx, tris)
     return b
 
@@ -39,7 +39,7 @@ for n in [int(x) for x in a.time.split(",") if x]:
     d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()
     hashes = {}
     for m in modes:
-        os.environ["BVH_HPLOC_MODE"] = m
+        ctx.set_option("hploc", m)
         b = pkg.HPLOC()
         for _ in range(3): b.build(ctx, d_tris, on_device=True, n=n)
         ctx.synchronize(); t0 = time.perf_counter()

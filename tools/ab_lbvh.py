@@ -14,7 +14,7 @@ for n in [int(x) for x in sys.argv[1:]] or [1000, 5000, 262144, 2000000, 1000000
         d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()
         res = {}
         for mode in ("single", "block"):
-            os.environ["BVH_LBVH_MODE"] = mode
+            ctx.set_option("lbvh", mode)
             b = pkg.SinglePassLbvh()
             for _ in range(3): b.build(ctx, d_tris, on_device=True, n=n)
             ctx.set_profiling(1); em = []

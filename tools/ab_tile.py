@@ -17,11 +17,11 @@ n = len(tris)
 d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()
 cks = {}
 for mode in ("async", "block"):
-    os.environ["BVH_HPLOC_MODE"] = mode
+    ctx.set_option("hploc", mode)
     b = pkg.HPLOC().build(ctx, d_tris, on_device=True, n=n)
     cks[mode] = b.checksum()
 print(f"{kind} n={n}: checksum async {cks['async']:016x} block {cks['block']:016x} {'EQUAL' if cks['async'] == cks['block'] else 'DIFFERENT'}", flush=True)
-os.environ["BVH_HPLOC_MODE"] = "block"
+ctx.set_option("hploc", "block")
 b = pkg.HPLOC()
 for _ in range(3): b.build(ctx, d_tris, on_device=True, n=n)
 ctx.set_profiling(2)

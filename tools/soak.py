@@ -18,7 +18,7 @@ def soak(pkg, orc, ctx, budget: float, seed: int, sizes=SIZES, max_random: int =
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     builds = 0; fails = []
-    saved = {v: os.environ.get(v) for v in ("BVH_HPLOC_MODE", "BVH_LBVH_MODE")}
+    saved = {k: ctx.get_option(k) for k in ("hploc", "lbvh")}
     try:
         while time.time() < t_end:
             n = int(rng.choice(sizes)) if rng.random() < 0.5 else int(np.exp(rng.uniform(np.log(2), np.log(max_random))))
@@ -32,8 +32,7 @@ def soak(pkg, orc, ctx, budget: float, seed: int, sizes=SIZES, max_random: int =
             for algo in (0, 1, 2, 3):
                 for mode in (("async", "single"), ("block", "block")) if algo != 2 else (("", ""),):
                     if time.time() > t_end + 30: break
-                    os.environ["BVH_HPLOC_MODE"] = mode[0]; os.environ["BVH_LBVH_MODE"] = mode[1]
-                    if not mode[0]: os.environ.pop("BVH_HPLOC_MODE"); os.environ.pop("BVH_LBVH_MODE")
+                    ctx.set_option("hploc", mode[0] or "auto"); ctx.set_option("lbvh", mode[1] or "auto")
                     b = pkg.BUILDERS[algo]().build_ex(ctx, n, tris=d_tris, morton_bits=bits); got = b.download()
                     ok = orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
                     k = got["sorted_keys"]; ok = ok and bool(np.all(k[1:] >= k[:-1]))
@@ -59,9 +58,8 @@ def soak(pkg, orc, ctx, budget: float, seed: int, sizes=SIZES, max_random: int =
                         log("FAIL " + fails[-1])
             d_tris.free()
     finally:
-        for v, old in saved.items():
-            if old is None: os.environ.pop(v, None)
-            else: os.environ[v] = old
+        for k, old in saved.items():
+            ctx.set_option(k, old)
     return builds, fails
 
 

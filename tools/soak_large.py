@@ -24,8 +24,7 @@ while time.time() < t_end:
     for algo in (1, 0, 3, 2):
         res = []
         for mode in (("async", "single"), ("block", "block")) if algo != 2 else (("", ""),):
-            if mode[0]: os.environ["BVH_HPLOC_MODE"] = mode[0]; os.environ["BVH_LBVH_MODE"] = mode[1]
-            else: os.environ.pop("BVH_HPLOC_MODE", None); os.environ.pop("BVH_LBVH_MODE", None)
+            ctx.set_option("hploc", mode[0] or "auto"); ctx.set_option("lbvh", mode[1] or "auto")
             got = pkg.BUILDERS[algo]().build_ex(ctx, n, tris=d_tris, morton_bits=bits).download()
             k = got["sorted_keys"]
             ok = orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0 and bool(np.all(k[1:] >= k[:-1]))

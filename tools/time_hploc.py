@@ -10,7 +10,7 @@ import bvh_pkg
 pkg = bvh_pkg.load(); ctx = pkg.Context(0)
 mode, n = sys.argv[1], int(sys.argv[2]); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 kind = sys.argv[4] if len(sys.argv) > 4 else "uniform"
-os.environ["BVH_HPLOC_MODE"] = mode
+ctx.set_option("hploc", mode)
 tris = pkg.meshgen.uniform(n, 1) if kind == "uniform" else pkg.meshgen.sponza_like(n, 3) if kind == "sponza" else pkg.meshgen.bunny_like(n, 2)
 n = len(tris)
 d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()
