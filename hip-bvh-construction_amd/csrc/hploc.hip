@@ -125,13 +125,98 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
     return w;
 }
 
+#ifndef HP_NN_LDS
+#define HP_NN_LDS 1        // 1: neighbour selection by LDS atomic minima (default); 0: round 1's alternative (two running minima in registers, the left
+#endif                     //    candidates' areas through ds_bpermute; needs more registers: spills at 7 waves per SIMD) for A/B builds
+// findNearestNeighbours (:83-117) of one PLOC round for the two tasks of a wave: every pair (slot, slot + r), r = 1..8, is evaluated ONCE, by its
+// lower end — neighbour boxes arrive through a DPP wave_shl:1 chain, two candidates per step so that the area arithmetic runs as packed f32 (same
+// operations, same association, no contraction; the min / max of the unions have no packed form) — and its 64-bit key {area bits, other end's slot} is
+// minimised into BOTH ends' words with LDS atomics (ds_min_u64: the reference's formulation; a wave's LDS operations execute in order, so the reset,
+// the atomics and the read-back need no barrier).  Returns the slot of the lane's nearest neighbour (lowest slot on equal areas).
+// nn: the wave's 64-entry LDS scratch.  ABL_*: in-situ cost probes of tools/ab_probe.sh (wrong trees, timing only; profiles/r03_hploc_bound.md).
+__device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int lane, int slot, u64* nn) {
+#if HP_NN_LDS
+    nn[lane] = ~0ull;
+    compiler_fence();                        // reset, atomics and read-back stay in program order
+#if HP_NN_LDS == 2
+    u32 abR = 0xFFFFFFFFu; int idR = 0;      // the lane's own right-hand candidates: running minimum in registers (strict <: lowest slot on equal areas)
+#endif
+#else
+    // two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the lower slot on ties), left
+    // candidates with decreasing slot (<= takes the lower slot), left beats right on ties
+    u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
+    const int la = lane << 2;
+#endif
+    Box nb = b;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 1; r <= HP_RADIUS; r += 2) {
+#ifdef ABL_NO_DPPMOV
+        const Box n1 = nb, n2 = nb;
+#else
+        const Box n1 = box_shl1(nb);                                     // box of slot + r
+        const Box n2 = box_shl1(n1);                                     // box of slot + r + 1
+#endif
+        nb = n2;
+        const v2f lx = { fminf(n1.lx, b.lx), fminf(n2.lx, b.lx) }, ly = { fminf(n1.ly, b.ly), fminf(n2.ly, b.ly) }, lz = { fminf(n1.lz, b.lz), fminf(n2.lz, b.lz) };
+        const v2f hx = { fmaxf(n1.hx, b.hx), fmaxf(n2.hx, b.hx) }, hy = { fmaxf(n1.hy, b.hy), fmaxf(n2.hy, b.hy) }, hz = { fmaxf(n1.hz, b.hz), fmaxf(n2.hz, b.hz) };
+        const v2f ex = hx - lx, ey = hy - ly, ez = hz - lz;
+        const v2f half_area = ex * ey + ex * ez + ey * ez;               // Aabb::area (:361-365): 2 * (xy + xz + yz)
+        const v2f area = half_area + half_area;                          // (x + x == 2 * x exactly)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rr = r + q;
+            const u32 ab = __float_as_uint(q ? area.y : area.x);
+#if defined(ABL_NO_ATOMIC)
+            (void)ab; (void)rr;
+#elif HP_NN_LDS == 1
+            if (act && (u32)(slot + rr) < cnt) {                         // both ends are clusters of this task
+                atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
+                atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
+            }
+#elif HP_NN_LDS == 2
+            // the pair's key goes to the FAR end's word only (an LDS instruction costs the tile kernel ~6 VALU instructions: profiles/r03_hploc_bound.md);
+            // the near end keeps its own candidates in registers
+            if (act && (u32)(slot + rr) < cnt) {
+                atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
+                if (ab < abR) { abR = ab; idR = slot + rr; }
+            }
+#else
+            const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * rr), (int)ab);   // area(slot - rr, slot)
+            if ((u32)(slot + rr) < cnt && ab < abR) { abR = ab; idR = slot + rr; }
+            if (slot >= rr && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - rr; }
+#endif
+        }
+    }
+    int probe = 0;
+#ifdef ABL_EXTRA_BPERM   // 8 more LDS crossbar operations per round
+#pragma unroll
+    for (int e = 0; e < 8; ++e) probe ^= __builtin_amdgcn_ds_bpermute(((lane + e) & 63) << 2, (int)__float_as_uint(b.lx) + e);
+#endif
+#ifdef ABL_EXTRA_VALU    // 192 more VALU operations per round (a dependent chain of v_mul, v_mov_dpp, v_add, v_min)
+    { float acc = b.lx;
+#pragma unroll
+      for (int e = 0; e < 48; ++e) acc = fminf(acc * 1.0000001f, dpp_shl1(acc) + b.ly);
+      probe ^= (int)__float_as_uint(acc); }
+#endif
+#if defined(ABL_NO_ATOMIC)
+    return (slot ^ 1) | (probe == 0x7fffabcd ? 64 : 0);
+#elif HP_NN_LDS == 1
+    compiler_fence();
+    return (int)(u32)nn[lane] | (probe == 0x7fffabcd ? 64 : 0);
+#elif HP_NN_LDS == 2
+    compiler_fence();
+    const u64 left = nn[lane];               // minimum over the pairs (slot - r, slot): lower slots, so it wins on equal areas
+    return ((u32)(left >> 32) <= abR ? (int)(u32)left : idR) | (probe == 0x7fffabcd ? 64 : 0);
+#else
+    return ((abL <= abR) ? idL : idR) | (probe == 0x7fffabcd ? 64 : 0);
+#endif
+}
+
 // PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
 // registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
 // read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
-#ifndef HP_NN_LDS
-#define HP_NN_LDS 1        // 1: neighbour selection by LDS atomic minima (default); 0: two running minima in registers (same speed, 246 -> 210 VALU/round)
-#endif
-// nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (HP_NN_LDS)
+// nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (nn_search)
 template <bool AGENT = true>
 __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, u64* nn) {
         const bool have = w.have, final_ = w.final_;
@@ -140,68 +225,21 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
         const u32 threshold = final_ ? 1u : HP_HALF;
         while (__ballot(have && cnt > threshold)) {
             const bool act = have && cnt > threshold;
-            // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
-            // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
-            // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
-#if HP_NN_LDS
-            // findNearestNeighbours (:83-117) as the reference does it: every pair's area is evaluated once and minimised, as the 64-bit key
-            // {area bits, neighbour slot}, into BOTH ends' words — LDS atomics (ds_min_u64; a wave's LDS operations execute in order, so the
-            // reset below, the atomics and the read-back need no barrier).  The selection costs no VALU work beyond the validity test.
-            nn[lane] = ~0ull;
-            compiler_fence();                        // reset, atomics and read-back stay in program order (the LDS executes a wave's operations in order)
-#else
-            // findNearestNeighbours (:83-117): minimum of {area bits, neighbour slot}; each pair's area is evaluated once.
-            // Two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the
-            // lower slot on ties), left candidates with decreasing slot (<= takes the lower slot), left beats right on ties.
-            u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
-            const int la = lane << 2;
-#endif
-            Box nb = b;
-            // two candidates per step so that the area arithmetic runs as packed f32 (v_pk_add/mul_f32: two lanes of a register pair
-            // per instruction); the min/max of the unions have no packed form.  Same operations, same association, no contraction.
-            typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int r = 1; r <= HP_RADIUS; r += 2) {
-                const Box n1 = box_shl1(nb);                                     // box of slot + r
-                const Box n2 = box_shl1(n1);                                     // box of slot + r + 1
-                nb = n2;
-                const v2f lx = { fminf(n1.lx, b.lx), fminf(n2.lx, b.lx) }, ly = { fminf(n1.ly, b.ly), fminf(n2.ly, b.ly) }, lz = { fminf(n1.lz, b.lz), fminf(n2.lz, b.lz) };
-                const v2f hx = { fmaxf(n1.hx, b.hx), fmaxf(n2.hx, b.hx) }, hy = { fmaxf(n1.hy, b.hy), fmaxf(n2.hy, b.hy) }, hz = { fmaxf(n1.hz, b.hz), fmaxf(n2.hz, b.hz) };
-                const v2f ex = hx - lx, ey = hy - ly, ez = hz - lz;
-                const v2f half_area = ex * ey + ex * ez + ey * ez;               // Aabb::area (:361-365): 2 * (xy + xz + yz)
-                const v2f area = half_area + half_area;                          // (x + x == 2 * x exactly)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int rr = r + q;
-                    const u32 ab = __float_as_uint(q ? area.y : area.x);
-#if HP_NN_LDS == 1
-                    if (act && (u32)(slot + rr) < cnt) {                         // both ends are clusters of this task
-                        atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
-                        atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
-                    }
-#else
-                    const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * rr), (int)ab);   // area(slot - rr, slot)
-                    if ((u32)(slot + rr) < cnt && ab < abR) { abR = ab; idR = slot + rr; }
-                    if (slot >= rr && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - rr; }
-#endif
-                }
-            }
+            const int nbr = nn_search(b, act, cnt, lane, slot, nn);
             // mergeClusters (:126-190)
-#if HP_NN_LDS == 1
-            compiler_fence();
-            const int nbr = (int)(u32)nn[lane];
-#else
-            const int nbr = (abL <= abR) ? idL : idR;
-#endif
             const int nsrc = hbase + nbr;
             const u32 nbr_of_nbr = (u32)__shfl(nbr, nsrc);
             const bool in = act && (u32)slot < cnt;
             const bool mutual = in && nbr_of_nbr == (u32)slot;
             const bool merge = mutual && slot < nbr;
             const bool absorbed = mutual && slot > nbr;
+#ifdef ABL_NO_BPERM
+            const u32 id_nb = id + 1u, rep_nb = rep + 1u; const Box bn = b;
+#else
             const u32 id_nb = (u32)__shfl((int)id, nsrc);
             const u32 rep_nb = (u32)__shfl((int)rep, nsrc);
             const Box bn = shfl_box(b, nsrc);
+#endif
             if (merge) {
                 b = box_union(b, bn);
                 u32 at = rep_nb - 1u;                            // the absorbed partner's rep is retired here, once
@@ -230,12 +268,124 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             const u32 kh = (u32)(__ballot(keep) >> hbase);
             const u32 newcnt = (u32)__popc(kh);
             const int dst = act ? (hbase + (keep ? (int)__popc(kh & ((1u << slot) - 1u)) : 31)) : lane;
+#ifdef ABL_NO_PERMUTE
+            id = id + (u32)dst; rep = rep ^ 1u;
+#else
             id = push_u32(dst, id); rep = push_u32(dst, rep);
             b.lx = push_f32(dst, b.lx); b.ly = push_f32(dst, b.ly); b.lz = push_f32(dst, b.lz);
             b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
+#endif
             if (act) { if ((u32)slot >= newcnt) id = INV; cnt = newcnt; }
         }
         w.id = id; w.rep = rep; w.cnt = cnt; w.b = b;
+}
+
+// ---- PLOC rounds on a work list that lives in LDS (round 3) -----------------------------------------------------------------------------
+// What binds the tile kernel is the LDS pipeline, not VALU issue (profiles/r03_hploc_bound.md: dropping all 42 DPP moves of a round changes nothing,
+// eight more ds_bpermute per round cost +32 %): a ds_bpermute / ds_permute / ds_min_u64 occupies the CU's LDS pipe for 6 cycles per wave-instruction
+// whatever it moves (4 bytes per lane for the crossbar operations), a ds_read_b64 for 2.  ploc_rounds above moves the partner's cluster (9
+// ds_bpermute) and compacts the list (8 ds_permute) through the crossbar: 102 of a round's ~206 LDS cycles.  Here the list stays in LDS as records:
+// the partner is READ (one 4-byte + three 8-byte reads: 10 cycles), survivors are WRITTEN to their rank (22) and every lane reads its new slot
+// back (10), the neighbour's choice is a 4-byte read of its key word instead of a ds_bpermute: ~150 cycles per round, and a task neither loads nor
+// stores its list around the rounds — the survivors already sit at the range's first positions, where the parent task expects them.
+// List: position -> record {id, rep, box}; positions of the task's slots: slot t < nl at base + t, the others at rbase + t (the two children's lists,
+// left-packed on the fly); after the first round everything is at base + t.
+// Tag: the list's own encoding of {id, rep} (the rounds only decode it where a node is written).  Every list access is unconditional (positions are
+// clamped by the caller) and branch-free: a divergent branch between two LDS reads makes them two dependent round trips.
+struct TileList {            // k_hploc_block: id / rep tile-relative in 16 bits (id: 0x8000 | k = leaf ni + g0 + k; k = node g0 + k; 0xFFFF = invalid)
+    typedef u32 Tag;         // id16 | rep16 << 16
+    u32* ir; float2* b0; float2* b1; float2* b2;     // {lx, ly} {lz, hx} {hy, hz}: 8-byte LDS accesses (2 LDS cycles per wave-instruction; a 4-byte one takes 4)
+    u32 g0, ni;
+    static __device__ __forceinline__ Tag invalid_tag() { return 0xFFFFFFFFu; }
+    static __device__ __forceinline__ bool is_valid(Tag t) { return (t & 0xFFFFu) != 0xFFFFu; }
+    __device__ __forceinline__ u32 id(Tag t) const { const u32 ie = t & 0xFFFFu; return g0 + ie + ((0u - (ie >> 15)) & (ni - 0x8000u)); }   // (valid tags only)
+    __device__ __forceinline__ u32 rep(Tag t) const { return g0 + (t >> 16); }
+    __device__ __forceinline__ Tag with_node(Tag t, u32 node) const { return (t & 0xFFFF0000u) | (node - g0); }
+    __device__ __forceinline__ void load(u32 pos, Tag& t, Box& b) const {
+        t = ir[pos];
+        const float2 q0 = b0[pos], q1 = b1[pos], q2 = b2[pos];
+        b = { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
+    }
+    __device__ __forceinline__ void store(u32 pos, Tag t, const Box& b) const {
+        ir[pos] = t; b0[pos] = make_float2(b.lx, b.ly); b1[pos] = make_float2(b.lz, b.hx); b2[pos] = make_float2(b.hy, b.hz);
+    }
+    __device__ __forceinline__ Tag tag_at(u32 pos) const { return ir[pos]; }
+    __device__ __forceinline__ void invalidate(u32 pos) const { ir[pos] = 0xFFFFFFFFu; }
+};
+// One task per 32-lane half.  In: have / final_ (uniform per half), cnt, and the lane's cluster (tag, b; invalid beyond cnt) as loaded from the list.
+// Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
+template <bool AGENT, typename List>
+__device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
+                                                const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn) {
+    typename List::Tag tag = tag_io;
+    u32 cnt = cnt_io;
+    Box b = b_io;
+    const u32 threshold = final_ ? 1u : HP_HALF;
+    bool moved = nl >= cnt;                           // every slot already sits at base + slot
+    while (__ballot(have && cnt > threshold)) {
+        const bool act = have && cnt > threshold;
+        const u32 nbr = (u32)nn_search(b, act, cnt, lane, slot, nn) & 31u;
+        // mergeClusters (:126-190): the neighbour's choice (low word of its key) and its record, read in one go
+        const bool in = act && (u32)slot < cnt;
+        const u32 pn = nbr < nl ? base + nbr : rbase + nbr;
+#if HP_NN_LDS == 1
+        const u32 nbr_of_nbr = (u32)nn[hbase + (int)nbr];              // (the key word's low half IS the neighbour's choice)
+#else
+        const u32 nbr_of_nbr = (u32)__shfl((int)nbr, hbase + (int)nbr);
+#endif
+        typename List::Tag tag_nb; Box bn;
+        list.load(pn < lim ? pn : lim, tag_nb, bn);
+        // the neighbour's key and record come back in ONE LDS round trip: without this the compiler sinks the box reads into the merge branch below,
+        // behind the wait for the key (a third dependent round trip per round)
+        asm volatile("" : "+v"(bn.lx), "+v"(bn.ly), "+v"(bn.lz), "+v"(bn.hx), "+v"(bn.hy), "+v"(bn.hz));
+        const bool mutual = in && nbr_of_nbr == (u32)slot;
+        const bool merge = mutual && (u32)slot < nbr;
+        const bool absorbed = mutual && (u32)slot > nbr;
+        // (the union, the node index and the new tag are computed by every lane and selected: loads that only feed a divergent branch are sunk into
+        // it by the compiler and then wait for the neighbour's key first — one more dependent LDS round trip per round)
+        const Box bu = box_union(b, bn);
+        u32 at = list.rep(tag_nb) - 1u;                      // the absorbed partner's rep is retired here, once
+        u32 l = list.id(tag), r = list.id(tag_nb);
+        if (merge) {
+            if (final_ && cnt == 2u && at != 0u) {
+                // the root must be node 0 (:165-167 makes the last allocation 0): move node 0's occupant to the root's natural slot and re-point its parent
+                const u64* q0 = reinterpret_cast<const u64*>(nodes);
+                u64* qs = reinterpret_cast<u64*>(nodes + at);
+                const u64 w0 = ld_agent(q0 + 0), w1 = ld_agent(q0 + 1), w2 = ld_agent(q0 + 2), w3 = ld_agent(q0 + 3);
+                st_agent(qs + 0, w0); st_agent(qs + 1, w1); st_agent(qs + 2, w2); st_agent(qs + 3, w3);
+                if (l == 0u) l = at;
+                else if (r == 0u) r = at;
+                else {
+                    const u32 pw = ld_agent(zero_parent);
+                    st_agent(reinterpret_cast<u32*>(nodes + (pw >> 1)) + (pw & 1u), at);
+                }
+                at = 0u;
+            } else if (l == 0u || r == 0u) st_agent(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
+            if (AGENT) node_store_agent(nodes + at, l, r, bu); else node_store_plain(nodes + at, l, r, bu);
+        }
+        b.lx = merge ? bu.lx : b.lx; b.ly = merge ? bu.ly : b.ly; b.lz = merge ? bu.lz : b.lz;
+        b.hx = merge ? bu.hx : b.hx; b.hy = merge ? bu.hy : b.hy; b.hz = merge ? bu.hz : b.hz;
+        tag = merge ? list.with_node(tag, at) : tag;
+        // compaction (:176-187): survivors and merged clusters write their record to their rank — in place: every read of this round has been issued
+        // (a wave's LDS operations execute in order) — and every lane reads the record of its slot back
+        const bool keep = in && !absorbed;
+        const u32 kh = (u32)(__ballot(keep) >> hbase);
+        const u32 newcnt = (u32)__popc(kh);
+        if (keep) list.store(base + (u32)__popc(kh & ((1u << slot) - 1u)), tag, b);
+        typename List::Tag t2; Box b2;
+        list.load(base + (u32)slot < lim ? base + (u32)slot : lim, t2, b2);
+        if (act) {
+            cnt = newcnt; nl = 32u; moved = true;
+            b = b2; tag = (u32)slot < newcnt ? t2 : List::invalid_tag();
+        }
+#ifdef ABL_EXTRA_TRIP    // in-situ probe: one more DEPENDENT LDS round trip per round (a 4-byte read whose address depends on the read-back, result waited for)
+        { u32 x = (u32)nn[(__float_as_uint(b.lx) >> 29) + (u32)(lane & 56)];
+          asm volatile("" : "+v"(x));
+          if (x == 0x12345u) cnt = 0u; }
+#endif
+    }
+    if (have && !moved && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);   // no round ran: left-pack the right child's clusters
+    tag_io = tag; cnt_io = cnt; b_io = b;
 }
 
 // ---- the asynchronous part: run ready merge tasks, two per pass (one per 32-lane half of the wave), then hand the finished
@@ -371,8 +521,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ K s_key[T + 2 * KM];                  // nodes) — with the margin in LDS none of them is a dependent global load; positions g0-KM .. g0+T+KM-1
     // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
     // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
-    __shared__ unsigned short e_id[T], e_rep[T];     // id: 0x8000 | k = leaf ni + g0 + k;  k = node g0 + k;  0xFFFF = invalid
-    __shared__ float e_b[6][T];
+    __shared__ u32 e_ir[T];                          // id | rep << 16, tile-relative (TileList)
+    __shared__ float2 e_bx[3 * T + 2];               // {lx, ly} | {lz, hx} | {hy, hz} per position; the three planes (T + 1) * 8 bytes apart so that the compiler cannot
+                                                     // fuse two plane accesses into one ds_read2(st64)_b64 (8 LDS cycles; two ds_read_b64 take 2 each)
+    float2* const e_b0 = e_bx; float2* const e_b1 = e_bx + T + 1; float2* const e_b2 = e_bx + 2 * T + 2;
     __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
     __shared__ u32 s_cnt[128], s_off[128];
@@ -386,7 +538,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     const u32 g0 = blockIdx.x * (u32)T;
     const u32 nleaf = (n - g0) < (u32)T ? (n - g0) : (u32)T;
     const u32 sub = blockIdx.x % HPQ_SUB;
-    auto decode_id = [&](u32 ie) -> u32 { return ie == 0xFFFFu ? INV : ((ie & 0x8000u) ? ni + g0 + (ie & 0x7FFFu) : g0 + ie); };
+    const TileList tl{ e_ir, e_b0, e_b1, e_b2, g0, ni };
 
     // ---- stage the block: leaves (SetupClusters :44-47, fused), keys -------------------------------------------------
 #pragma unroll
@@ -398,10 +550,19 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             float* f = reinterpret_cast<float*>(leaves + g);
             reinterpret_cast<u32*>(f)[0] = prim;
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-            e_id[k] = (unsigned short)(0x8000u | k); e_rep[k] = (unsigned short)k;
-            e_b[0][k] = b.lx; e_b[1][k] = b.ly; e_b[2][k] = b.lz; e_b[3][k] = b.hx; e_b[4][k] = b.hy; e_b[5][k] = b.hz;
+            e_ir[k] = 0x8000u | k | (k << 16);
+            e_b0[k] = make_float2(b.lx, b.ly); e_b1[k] = make_float2(b.lz, b.hx); e_b2[k] = make_float2(b.hy, b.hz);
         }
     }
+#ifdef ABL_DOUBLE_STAGE   // in-situ probe: the tile's gather a second time (other leaves), nothing stored: is the staging exposed or hidden under other tiles' rounds?
+    {   float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const u32 k = (u32)tid + (u32)i * NT;
+            if (k < nleaf) { const u32 g = (g0 + k + n / 2u) % n; const Box b = box_load(boxes + svals[g]); acc += b.lx + b.ly + b.lz + b.hx + b.hy + b.hz; }
+        }
+        if (__float_as_uint(acc) == 0x7fffabcdu) e_ir[0] = 0u; }
+#endif
     for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
     if (tid < 128) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; }
@@ -465,28 +626,22 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const bool have = t < c;
             u32 P = 0, L = 0, R = 0;
             if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0xFFFFu; R = rg >> 16; }
-            // loadIndices (:192-206) from the LDS work lists: the first <= 16 valid entries of each child range
+            // loadIndices (:192-206) from the LDS work lists: the first <= 16 valid entries of each child range, left-packed on the fly; the rounds
+            // run on the list in place and leave the survivors at the range's first positions (storeIndices :208-218)
             const bool is_left = slot < 16;
             const u32 kk = (u32)(slot & 15);
             const u32 c_start = is_left ? L : P + 1u, c_len = is_left ? (P - L + 1u) : (R - P);
-            u32 idv = 0xFFFFu;
-            if (have && kk < c_len) idv = e_id[c_start + kk];
-            const u32 vb = (u32)(__ballot(idv != 0xFFFFu) >> hbase);
+            const bool ok = have && kk < c_len && TileList::is_valid(tl.tag_at(c_start + kk));
+            const u32 vb = (u32)(__ballot(ok) >> hbase);
             const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb >> 16);
-            HpWork w; w.have = have; w.final_ = false; w.tL = g0 + L; w.cnt = nl + nr;
-            w.id = INV; w.rep = INV; w.b = box_empty();
-            if (have && (u32)slot < w.cnt) {
-                const u32 sp = (u32)slot < nl ? L + (u32)slot : P + 1u + ((u32)slot - nl);
-                w.id = decode_id(e_id[sp]); w.rep = g0 + e_rep[sp];
-                w.b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
-            }
-            ploc_rounds<false>(w, nodes, zero_parent, ni, lane, slot, hbase, s_nn[wave]);
-            if (have && slot < 16) {                 // storeIndices (:208-218) into the range's first 16 positions
-                const u32 d = L + (u32)slot;
-                e_id[d] = (unsigned short)(w.id == INV ? 0xFFFFu : (w.id >= ni ? 0x8000u | (w.id - ni - g0) : w.id - g0));
-                e_rep[d] = (unsigned short)(w.rep - g0);
-                e_b[0][d] = w.b.lx; e_b[1][d] = w.b.ly; e_b[2][d] = w.b.lz; e_b[3][d] = w.b.hx; e_b[4][d] = w.b.hy; e_b[5][d] = w.b.hz;
-            }
+            u32 cnt = nl + nr;
+            const u32 rbase = P + 1u - nl;
+            const u32 sp = (u32)slot < nl ? L + (u32)slot : rbase + (u32)slot;
+            TileList::Tag tag; Box b;
+            tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
+            if (!(have && (u32)slot < cnt)) tag = TileList::invalid_tag();
+            ploc_rounds_lds<false>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, slot, hbase, s_nn[wave]);
+            if (have && (u32)slot >= cnt && slot < 16) tl.invalidate(L + (u32)slot);          // INVALID-terminated
         }
         __syncthreads();
     }
@@ -546,8 +701,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 const u32 rg = m_range[tk & 0x7FFFu];
                 const u32 Lr = rg & 0xFFFFu; L = g0 + Lr; R = g0 + (rg >> 16); right = (tk & 0x8000u) != 0u;
                 const u32 sp = Lr + (u32)sl;
-                const Box b = { e_b[0][sp], e_b[1][sp], e_b[2][sp], e_b[3][sp], e_b[4][sp], e_b[5][sp] };
-                node_store_plain(recs + L + sl, decode_id(e_id[sp]), g0 + e_rep[sp], b);     // read by k_hploc_ext: the kernel boundary orders it
+                TileList::Tag tg; Box b;
+                tl.load(sp, tg, b);
+                node_store_plain(recs + L + sl, TileList::is_valid(tg) ? tl.id(tg) : INV, tl.rep(tg), b);     // read by k_hploc_ext: the kernel boundary orders it
             }
             if (on && sl == 0) {                     // lane 0 of each group moves the parent's count
                 const u32 q = right ? L - 1u : R;

@@ -49,6 +49,17 @@ def ctx(pkg):
     c.close()
 
 
+def require_ref(present, what: str) -> None:
+    """The reference-side pins (oracle/_ref/: binaries built from /root/reference by oracle/Makefile, git-ignored, shipped to the GPU box with the
+    snapshot) must not vanish silently: a missing piece FAILS the test unless BVH_ALLOW_NO_REF=1 says the run is knowingly without them."""
+    if present:
+        return
+    msg = f"{what} is missing (make -C oracle ref, in the container that has /root/reference); set BVH_ALLOW_NO_REF=1 to skip the reference-side checks"
+    if os.environ.get("BVH_ALLOW_NO_REF") == "1":
+        pytest.skip(msg)
+    pytest.fail(msg)
+
+
 @pytest.fixture
 def sched_opts(ctx):
     """sched_opts(hploc="block", lbvh="block", sort_knobs=8, ploc="persistent") sets bvh_ctx options on the session ctx for one test; all are reset afterwards.

@@ -1,8 +1,10 @@
 """GPU, BASELINE.json's full sizes (10 M-triangle uniform mesh; 262 144-triangle Sponza-class mesh): size-independent properties —
 sortedness and permutation of the sort output, structural validity of the tree (every primitive reachable exactly once, every
 internal box = union of its children, bit exact), root box = scene extent, the two HPLOC schedulers agree on the topology, and the
-device-side SAH equals the CPU evaluation of the downloaded tree.  (The oracle itself is run at these sizes only where it finishes
-in seconds: the LBVH emitters.)"""
+device-side SAH equals the CPU evaluation of the downloaded tree — and, since round 3, the ORACLE's own tree at the headline size: the
+committed goldens of tools/make_golden.py fullsize (tests/golden/reference_outputs.json "_fullsize": topology hash, f64 SAH, leaf / node
+FNV of the pinned CPU oracle on uniform(10 M, 1) and uniform(2 M, 100)) plus a live oracle run (11 s at 10 M)."""
+import json
 import os
 
 import numpy as np
@@ -11,6 +13,12 @@ import pytest
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
 N_FULL = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def fullsize_golden():
+    from conftest import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "reference_outputs.json")))["_fullsize"]
 
 
 @pytest.fixture(scope="module")
@@ -29,9 +37,10 @@ def _check_common(pkg, orc, got, tris, scene):
     assert np.array_equal(root["min"], scene["min"][0]) and np.array_equal(root["max"], scene["max"][0])
 
 
-def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
+def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big, fullsize_golden):
     n = len(big)
     _, scene = orc.prim_bounds(big)
+    gold = fullsize_golden["uniform10000000_s1"]["hploc"]
     hashes, sahs = [], []
     for mode in ("block", "async"):
         with ctx.options(hploc=mode):
@@ -43,7 +52,14 @@ def test_hploc_10m_properties_and_scheduler_agreement(pkg, orc, ctx, big):
         s_cpu = orc.sah_bvh2(got["nodes"], got["leaves"], 0, n, 1)[0]
         assert abs(b.sah_cost() - s_cpu) <= 1e-9 * s_cpu
         sahs.append(s_cpu)
+        # BASELINE.json config 3 against the pinned oracle (committed golden): same leaves, same canonical topology, SAH within 1e-4
+        assert "%016x" % orc.fnv1a(got["leaves"]) == gold["leaves_fnv"], mode
+        assert "%016x" % hashes[-1] == gold["topology"], f"{mode}: HPLOC topology at 10 M differs from the oracle's"
+        assert abs(s_cpu - gold["sah_f64"]) <= 1e-4 * gold["sah_f64"]
     assert hashes[0] == hashes[1], "block-local and asynchronous HPLOC schedulers must build the same tree"
+    # and the oracle run live on this box reproduces its own golden (the fixture is not stale)
+    ref = orc.build_tree(3, big)
+    assert "%016x" % orc.topology_hash(ref["nodes"], ref["leaves"], 0, n, 1) == gold["topology"] and ref["stats"]["merge_calls"] == gold["stats"]["merge_calls"]
 
 
 def test_hploc_ticket_climb_on_clustered_60bit_keys(pkg, orc, ctx):
@@ -80,7 +96,7 @@ def test_lbvh_10m_bit_exact(pkg, orc, ctx, big, algo):
     assert got["nodes"].tobytes() == ref.tobytes()
 
 
-def test_ploc_10m_properties(pkg, orc, ctx, big):
+def test_ploc_10m_properties(pkg, orc, ctx, big, fullsize_golden):
     n = len(big)
     _, scene = orc.prim_bounds(big)
     b = pkg.PLOCNew().build(ctx, big)
@@ -88,6 +104,27 @@ def test_ploc_10m_properties(pkg, orc, ctx, big):
     _check_common(pkg, orc, got, big, scene)
     s_cpu = orc.sah_bvh2(got["nodes"], got["leaves"], 0, n, 1)[0]
     assert abs(b.sah_cost() - s_cpu) <= 1e-9 * s_cpu
+    # against the pinned oracle at 10 M (committed golden): PLOC++ node arrays are byte-identical (deterministic numbering), same iteration count
+    gold = fullsize_golden["uniform10000000_s1"]["ploc"]
+    assert "%016x" % orc.fnv1a(got["leaves"]) == gold["leaves_fnv"] and "%016x" % orc.fnv1a(got["nodes"]) == gold["nodes_fnv"]
+    assert b.timings.ploc_iterations == gold["stats"]["iterations"]
+    assert abs(s_cpu - gold["sah_f64"]) <= 1e-4 * gold["sah_f64"]
+
+
+def test_config5_mesh_2m_vs_oracle_golden(pkg, orc, ctx, fullsize_golden):
+    """config 5's first mesh, uniform(2 000 000, seed 100): HPLOC / PLOC++ / single-pass LBVH against the committed oracle outputs"""
+    tris = pkg.meshgen.uniform(2_000_000, 100); n = len(tris)
+    g = fullsize_golden["uniform2000000_s100"]
+    d = ctx.upload(tris)
+    for algo, tag in ((3, "hploc"), (2, "ploc"), (1, "lbvh_single")):
+        got = pkg.BUILDERS[algo]().build_ex(ctx, n, tris=d).download()
+        assert "%016x" % orc.fnv1a(got["sorted_keys"]) == g["sorted_keys_fnv"] and "%016x" % orc.fnv1a(got["sorted_vals"]) == g["sorted_vals_fnv"]
+        assert "%016x" % orc.topology_hash(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == g[tag]["topology"], tag
+        if tag != "hploc":
+            assert "%016x" % orc.fnv1a(got["nodes"]) == g[tag]["nodes_fnv"] and got["root"] == g[tag]["root"], tag
+        s = orc.sah_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"])[0]
+        assert abs(s - g[tag]["sah_f64"]) <= 1e-4 * g[tag]["sah_f64"]
+    d.free()
 
 
 def test_sponza_262k_all_builders_vs_oracle(pkg, orc, ctx):

@@ -5,6 +5,8 @@ reference) identical canonical topology + SAH within 1e-4 relative (north_star t
 import numpy as np
 import pytest
 
+from conftest import require_ref
+
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 SAH_RTOL = 1e-4   # BASELINE.json north_star: "match SAH cost within 1e-4 for PLOC variants"
@@ -157,6 +159,7 @@ def test_collapse4(pkg, orc, ctx, cases, name, algo):
     c_got = orc.sah_bvh4(wide, prims, boxes, total, n)[0]; c_orc = orc.sah_bvh4(ow, opn, boxes, ototal, n)[0]
     assert abs(c_got - c_orc) <= 1e-9 * c_orc
     R = orc.ref_utility()
+    require_ref(R is not None, "oracle/_ref/libref_utility.so (the reference's Utility.cpp)")
     if R is not None:
         w = np.ascontiguousarray(wide); p = np.ascontiguousarray(prims)
         depth_ok = n <= 60_000                      # the reference validator's DFS stack is 64 entries

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, require_ref
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
@@ -69,6 +69,7 @@ def test_bvh4_cost_on_device(pkg, orc, ctx, algo, name, n):
     c64, c32 = orc.sah_bvh4(wide, prims, boxes, total, n)
     assert cost == pytest.approx(c64, rel=1e-6)
     R = orc.ref_utility()
+    require_ref(R is not None, "oracle/_ref/libref_utility.so (the reference's Utility.cpp)")
     if R is not None:
         w = np.ascontiguousarray(wide); p = np.ascontiguousarray(prims)
         # the reference accumulates in f32 in node-index order (0.2 % off at 262 k): the oracle's f32 emulation of exactly that loop reproduces it,

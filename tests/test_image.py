@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, require_ref
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 W = 512          # the reference's image size (src/TwoPassLbvh.cpp:219-220)
@@ -50,8 +50,7 @@ def test_image_pixel_exact_vs_oracle(pkg, orc, ctx, views, scene, algo):
 
 @pytest.mark.parametrize("scene", ["cornell382", "sponza_40k"])
 def test_image_vs_reference_kernels(pkg, orc, ctx, views, scene):
-    if not os.path.exists(orc.REF_DRIVER):
-        pytest.skip("oracle/_ref not built")
+    require_ref(os.path.exists(orc.REF_DRIVER), "oracle/_ref/libref_driver.so (the reference's kernels)")
     tris, cam, xf = views[scene]; n = len(tris)
     b = pkg.PLOCNew().build(ctx, tris)
     rgba, rays = b.render(tris, cam, xf, W)

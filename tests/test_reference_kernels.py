@@ -1,23 +1,27 @@
 """The REFERENCE's own device kernels (src/*Kernel.h compiled unmodified into oracle/_ref/*.co, launched by
 oracle/ref_driver.cpp) executed on the MI355X and compared with (a) the CPU oracle — this is what pins the oracle to the
-reference — and (b) the product's HIP path.  Skipped when oracle/_ref was not built (it is built in the dev container from
-/root/reference and travels to the GPU box as binaries)."""
+reference — and (b) the product's HIP path.  oracle/_ref is built in the dev container from /root/reference and travels to the GPU box as binaries; if it is
+missing these tests FAIL (conftest.require_ref) unless BVH_ALLOW_NO_REF=1."""
 import os
 
 import numpy as np
 import pytest
+
+from conftest import require_ref
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
 @pytest.fixture(scope="module")
 def drv(orc):
-    if not os.path.exists(orc.REF_DRIVER):
-        pytest.skip("oracle/_ref not built")
+    require_ref(os.path.exists(orc.REF_DRIVER), "oracle/_ref/libref_driver.so (the reference's kernels)")
     return orc
 
 
-MESHES = [("uniform", 1000, 21), ("uniform", 50_000, 22), ("uniform", 33, 23), ("uniform", 65, 24), ("sponza", 40_000, 3), ("bunny", 30_000, 2)]
+MESHES = [("uniform", 1000, 21), ("uniform", 50_000, 22), ("uniform", 33, 23), ("uniform", 65, 24), ("sponza", 40_000, 3), ("bunny", 30_000, 2),
+          # the configs' own sizes (round 3): BASELINE.json config 2 = Sponza-class 262 144 single-pass LBVH "bit-exact node layout vs reference",
+          # config 1's Bunny-class 150 000, and 1 M (above the tile schedulers' thresholds: the product's large-input kernels vs the reference's)
+          ("sponza", 262_144, 3), ("bunny", 150_000, 2), ("uniform", 1_000_000, 1)]
 
 
 def _mesh(pkg, kind, n, seed):

@@ -15,6 +15,10 @@
       ones: FNV-1a of the node array, canonical topology hash, SAH, host-loop iterations — merged into reference_outputs.json under
       "_ploc_emulated"; and of its two CollapseToWide4Bvh kernels (whole grid resident; on the GPU they hang unless every workgroup is) under
       "_collapse_emulated".  The reference's Ploc kernel cannot run on wave64 hardware, so this is its only executable form here.
+  step 4 (anywhere; CPU only, ~1 min):  python tools/make_golden.py fullsize
+      The pinned CPU oracle on the configs' own sizes: uniform(10 000 000, seed 1) (config 3: HPLOC; also PLOC++) and uniform(2 000 000, seed 100)
+      (config 5's first mesh: HPLOC, PLOC++, single-pass LBVH): canonical topology hash, f64 SAH, FNV-1a of leaves / node array, PLOC++ iterations,
+      and the oracle's exact cluster loads / stores / merge calls / NN rounds (the L, S of SURVEY.md §8(d)'s byte formulas) -> "_fullsize".
 Fixtures are data (inputs and expected outputs); no reference source text is stored.
 """
 import json
@@ -134,8 +138,39 @@ def make_reference(out_path):
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
 
 
+def make_fullsize():
+    import time
+    import bvh_pkg
+    import oracle as orc
+    pkg = bvh_pkg.load()
+    path = os.path.join(GOLDEN, "reference_outputs.json")
+    res = json.load(open(path))
+    out = {}
+    for name, n, seed, algos in (("uniform10000000_s1", 10_000_000, 1, (3, 2)), ("uniform2000000_s100", 2_000_000, 100, (3, 2, 1))):
+        tris = pkg.meshgen.uniform(n, seed)
+        e = {"n": n, "generator": f"meshgen.uniform({n}, {seed})"}
+        for algo in algos:
+            t0 = time.time(); t = orc.build_tree(algo, tris); dt = time.time() - t0
+            tag = {1: "lbvh_single", 2: "ploc", 3: "hploc"}[algo]
+            lay = t["layout"]
+            assert orc.validate_bvh2(t["nodes"], t.get("leaves"), t["root"], n, lay) == 0
+            e[tag] = {"topology": "%016x" % orc.topology_hash(t["nodes"], t.get("leaves"), t["root"], n, lay), "sah_f64": orc.sah_bvh2(t["nodes"], t.get("leaves"), t["root"], n, lay)[0],
+                      "nodes_fnv": "%016x" % orc.fnv1a(t["nodes"]), "root": int(t["root"])}
+            if t.get("leaves") is not None:
+                e[tag]["leaves_fnv"] = "%016x" % orc.fnv1a(t["leaves"])
+            if "stats" in t:
+                e[tag]["stats"] = {k: int(v) for k, v in t["stats"].items()}
+            print(name, tag, "%.1f s" % dt, e[tag], flush=True)
+        e["sorted_keys_fnv"] = "%016x" % orc.fnv1a(t["skeys"]); e["sorted_vals_fnv"] = "%016x" % orc.fnv1a(t["svals"])
+        out[name] = e
+    res["_fullsize"] = out
+    json.dump(res, open(path, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 2 and sys.argv[1] == "meshes":
+    if len(sys.argv) >= 2 and sys.argv[1] == "fullsize":
+        make_fullsize()
+    elif len(sys.argv) >= 2 and sys.argv[1] == "meshes":
         make_meshes()
     elif len(sys.argv) >= 2 and sys.argv[1] == "ploc":
         make_ploc()
