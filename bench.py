@@ -9,8 +9,13 @@ root AABBs (RCCL) per step.  scaling = weak.  value = triangles built by all ran
 
 Also reported on the same JSON line:
   roofline     — dominant kernel's algorithmic bytes / its HIP-event time (events recorded on the launch stream inside the
-                 timed region) against the 8 TB/s HBM peak;
+                 timed region) against the 8 TB/s HBM peak; roofline.issue = how busy the VALUs and the LDS pipe are in that kernel
+                 (from the committed counter file profiles/issue_counters.json: the second bound of a kernel that is not HBM-bound);
   cpu_baseline — the reference's CPU binned-SAH builder (oracle port, 1 thread) timed on a bounded sample of the same mesh.
+Algorithmic bytes of the PLOC-family emit stages are exact per mesh: profiles/algorithmic_bytes.json, written by
+tools/algorithmic_bytes.py from the pinned oracle's cluster-load / store counts; the split of the HPLOC emit between its two kernels is the
+measured task share of profiles/hploc_task_share.json (tools/measure_task_share.py).  Both are data files: nothing here calls the oracle outside
+the cpu_baseline leg.
 """
 from __future__ import annotations
 
@@ -50,6 +55,32 @@ KERNEL_OWN_BYTES_PER_PRIM = {"k_hploc_block": 100.0, "k_hploc_ext": 40.0}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def _load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def exact_bytes(workload: str):
+    """(emit bytes / prim, SetupClusters bytes / prim, pipeline bytes / prim, source) of a PLOC-family workload from profiles/algorithmic_bytes.json, or None"""
+    tab = _load_json("algorithmic_bytes.json") or {}
+    e = tab.get(workload)
+    return None if not e else (e["emit_bytes_per_prim"], e["setup_bytes_per_prim"], e["pipeline_bytes_per_prim"], e["source"])
+
+
+def kernel_bytes_per_prim(name: str, algo: str, workload: str):
+    """algorithmic bytes per primitive of one kernel of this workload: exact per-mesh figures where the oracle supplies them, SURVEY.md §8(d)'s constants otherwise"""
+    ex = exact_bytes(workload)
+    if ex and name in ("k_hploc_block", "k_hploc_ext", "k_hploc", "k_ploc_iter"):
+        emit, setup = ex[0], ex[1]
+        if name in ("k_hploc", "k_ploc_iter"):
+            return setup + emit, "exact: " + ex[3]
+        share = (_load_json("hploc_task_share.json") or {}).get("tile_kernel_share", 0.85)        # merge tasks run by the tile kernel (measured; round 2 assumed 0.85)
+        return (setup + share * emit, f"exact, tile-kernel task share {share}") if name == "k_hploc_block" else ((1.0 - share) * emit, f"exact, tile-kernel task share {share}")
+    return KERNEL_BYTES_PER_PRIM.get(f"{algo}:{name}", KERNEL_BYTES_PER_PRIM.get(name, 0.0)), "SURVEY.md 8(d) constant"
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,9 +104,13 @@ def main() -> None:
     torch.cuda.set_device(local)
     dist = None
     backend = os.environ.get("BVH_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only to exercise the N>1 path on one GPU
-    if world > 1:
+    # BVH_BENCH_FORCE_GATHER=1: run the multi-GPU exchange (process group, staging copy, all-gather, max-over-ranks reduction) even at world size 1,
+    # so that the exact code path of an N-GPU run executes on a one-GPU box (tests/test_gpu_round3.py)
+    gather = world > 1 or os.environ.get("BVH_BENCH_FORCE_GATHER") == "1"
+    if gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -103,7 +138,7 @@ def main() -> None:
     ctx.reserve(n)
     builder = pkg.BUILDERS[algo]()
     root_box = torch.zeros(6, dtype=torch.float32, device="cuda")
-    gathered = torch.zeros(6 * world, dtype=torch.float32, device="cuda") if world > 1 else None
+    gathered = torch.zeros(6 * world, dtype=torch.float32, device="cuda") if gather else None
     lib = pkg.lib()
     import ctypes as C
 
@@ -111,7 +146,7 @@ def main() -> None:
 
     def step():
         builder.build(ctx, d_tris, on_device=True, n=n)
-        if world > 1:
+        if gather:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)); gather_events.append(ev)
             ev[0].record(side)
             # root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
@@ -126,7 +161,7 @@ def main() -> None:
             ev[1].record(side)
 
     def barrier():
-        if world > 1:
+        if gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,14 +182,14 @@ def main() -> None:
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if gather:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()
     # all-gather of the root boxes: mean / max over the timed steps on this rank, device time incl. the 24-byte staging copy
     gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_events[-args.steps:]] if gather_events else []
-    if world > 1 and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
+    if gather and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
         torch.cuda.synchronize()
         assert torch.equal(gathered[6 * rank: 6 * rank + 6], root_box), "all-gather of root AABBs is inconsistent"
     ctx.set_kernel_sampling(1); ctx.set_profiling(1)
@@ -163,12 +198,15 @@ def main() -> None:
     sah = builder.sah_cost()
 
     if rank != 0:
-        if world > 1:
+        if gather:
             dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
     value = (n * world) / (elapsed / args.steps) / 1e6
+    workload = f"{args.mesh}_{n}_tris_{args.algo}"
+    ex = exact_bytes(workload)
+    pipeline_bytes = int(round(ex[2] * n)) if ex else int(builder.timings.bytes_algorithmic)
     # ---- roofline of the dominant kernel (largest summed event time)
     roof = None
     if ktimes:
@@ -176,7 +214,7 @@ def main() -> None:
         name, (ms_sum, launches) = dom
         per_build_ms = ms_sum / n_sampled                       # all launches of that kernel in one (sampled) build
         launches_per_build = launches / n_sampled
-        per_prim = KERNEL_BYTES_PER_PRIM.get(f"{args.algo}:{name}", KERNEL_BYTES_PER_PRIM.get(name, 0.0))
+        per_prim, bytes_source = kernel_bytes_per_prim(name, args.algo, workload)
         alg_bytes = per_prim * n * (launches_per_build if name == "k_onesweep" else 1.0)
         achieved = alg_bytes / (per_build_ms * 1e-3) / 1e9 if per_build_ms > 0 else 0.0
         traffic = None
@@ -189,7 +227,16 @@ def main() -> None:
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms_sum / launches, 4), "launches_per_step": launches_per_build,
-                "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_build, 1.0) if name == "k_onesweep" else alg_bytes}
+                "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_build, 1.0) if name == "k_onesweep" else alg_bytes,
+                "algorithmic_bytes_per_prim": round(per_prim, 3), "algorithmic_bytes_source": bytes_source}
+        # the second bound: VALU / LDS pipe occupancy of this kernel from the committed SQ counters (profiles/issue_counters.json, written by
+        # tools/prof_round.sh from a rocprofv3 --pmc pass of this command; recompute: insts x cycles_per_inst / (units x launch cycles))
+        ic = (_load_json("issue_counters.json") or {}).get(f"{name}@{n}")
+        if ic:
+            cyc = ic["SQ_BUSY_CYCLES"] / ic["shader_engines"]                                    # launch length in shader cycles
+            roof["issue"] = {"valu_busy_frac": round(ic["SQ_INSTS_VALU"] * ic["cycles_per_valu_inst"] / (ic["simds"] * cyc), 4),
+                             "lds_busy_frac": round(ic["SQ_INSTS_LDS"] * ic["cycles_per_lds_inst"] / (ic["cus"] * cyc), 4),
+                             "waves_parked_frac": round(ic["SQ_WAIT_ANY"] / ic["SQ_WAVE_CYCLES"], 4), "source": "profiles/issue_counters.json"}
         if name in KERNEL_OWN_BYTES_PER_PRIM:     # the same kernel against the bytes it really has to move (work lists stay in LDS)
             own = KERNEL_OWN_BYTES_PER_PRIM[name] * n
             roof["own_bytes_per_launch"] = own; roof["own_frac"] = round(own / (per_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -209,20 +256,20 @@ def main() -> None:
         "metric": "bvh_build_throughput", "value": round(value, 2), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u32",
         "data": "synthetic",
-        "config": {"workload": f"{args.mesh}_{n}_tris_{args.algo}", "builder": pkg.ALGO_NAMES[algo], "tris_per_gpu": n, "mesh": args.mesh,
+        "config": {"workload": workload, "builder": pkg.ALGO_NAMES[algo], "tris_per_gpu": n, "mesh": args.mesh,
                    "seed": "1+rank", "parallelism": f"scene-shard x{world}" + (" + allgather(root aabb)" if world > 1 else "")},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "kernel_ms_per_step": {k: round(v[0] / n_sampled, 4) for k, v in ktimes.items()},     # from the sampled builds of the timed region
         "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds",
         "sah_bvh2": round(sah, 4),
-        "pipeline_roofline": {"algorithmic_bytes": int(builder.timings.bytes_algorithmic),
-                              "achieved_GBs": round(builder.timings.bytes_algorithmic / (ms_per_step * 1e-3) / 1e9, 1),
-                              "frac": round(builder.timings.bytes_algorithmic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "pipeline_roofline": {"algorithmic_bytes": pipeline_bytes, "source": ("exact: " + ex[3]) if ex else "SURVEY.md 8(d) constants (bvh_timings.bytes_algorithmic)",
+                              "achieved_GBs": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              "frac": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": roof, "cpu_baseline": cpu, "mesh_gen_s": round(gen_s, 2),
         "allgather_us": ({"mean": round(float(np.mean(gather_us)), 2), "max": round(float(np.max(gather_us)), 2), "bytes_per_rank": 24} if gather_us else None),
     }
     print(json.dumps(out))
-    if world > 1:
+    if gather:
         dist.destroy_process_group()
 
 

@@ -253,6 +253,13 @@ int bvh_ctx_set_option(bvh_ctx* c, bvh_option option, int64_t value) {
     return 0;
 }
 int bvh_ctx_get_option(const bvh_ctx* c, bvh_option option, int64_t* value_out) {
+#ifdef BVH_ABLATION   // measurement build only: option 1000 = merge tasks the HPLOC tile kernel ran in the last build (tools/measure_task_share.py)
+    if (c && value_out && (int)option == 1000) {
+        u32 v = 0; Bind b(c->device);
+        if (!c->hploc.queue_count || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->hploc.queue_count + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) return BVH_E_INTERNAL;
+        *value_out = v; return 0;
+    }
+#endif
     if (!c || !value_out || (int)option < 0 || (int)option > 3) return BVH_E_INVALID_ARG;
     *value_out = c->options[(int)option];
     return 0;

@@ -615,6 +615,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)((u32)tid + (u32)i * NT);
     __syncthreads();
     if (dbg == 2) return;
+#ifdef BVH_ABLATION       // measurement build: merge tasks run by the tile kernel (word 2 of sub-queue 0's padded head; read through BVH_OPT_DEBUG_TASKS_LOCAL)
+    if (tid == 0) { u32 t = 0; for (int lv = 0; lv < NLEV; ++lv) t += s_cnt[lv]; atomicAdd(q_count + 2, t); }
+#endif
 
     // ---- local hierarchy, deepest level first; two tasks per wave pass ----------------------------------------------------
     for (int lv = 0; lv < NLEV; ++lv) {

@@ -1,0 +1,110 @@
+"""GPU, round 3: the bench's real multi-GPU code path before the driver runs it (process group, staging copy, RCCL all-gather, max-over-ranks
+reduction) at world size 1 and — where the box has them — 2 ranks; the 2-rank gloo flavour on one device; the per-context option API that
+replaced the library's getenv knobs; the bvh_timings.sampled flag."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_bench(nproc, extra_env, args=("--tris", "200000", "--steps", "3", "--warmup", "1", "--cpu-sample", "0")):
+    env = dict(os.environ); env.update(extra_env); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                   # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_nccl_gather_path_world1():
+    """`bench.py` as the driver launches it (torch.distributed.run), the nccl branch of the exchange forced on at world size 1"""
+    out = _run_bench(1, {"BVH_BENCH_FORCE_GATHER": "1"})
+    assert out["n_gpus"] == 1 and out["allgather_us"] is not None and out["allgather_us"]["bytes_per_rank"] == 24 and out["allgather_us"]["mean"] > 0
+    assert out["value"] > 0 and out["roofline"]["kernel"].startswith("k_")
+
+
+def test_bench_nccl_two_ranks_when_two_devices():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: the 2-rank RCCL run needs two")
+    out = _run_bench(2, {})
+    assert out["n_gpus"] == 2 and out["allgather_us"] is not None and out["scaling"] == "weak"
+
+
+def test_bench_gloo_two_ranks_on_one_device():
+    """the N > 1 control flow (per-rank meshes, barrier, max over ranks, one JSON line from rank 0) with two ranks sharing the device"""
+    out = _run_bench(2, {"BVH_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["allgather_us"] is not None
+    assert out["config"]["tris_per_gpu"] == 200000 and out["value"] > 0
+
+
+def test_ctx_options_replace_env_knobs(pkg, orc, ctx):
+    L = pkg.lib()
+    v = C.c_int64()
+    for opt in range(4):
+        assert L.bvh_ctx_get_option(ctx.handle, opt, C.byref(v)) == 0 and v.value == 0          # defaults: decide by size, no test knobs
+    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_HPLOC_SCHEDULER, 3) == -10001
+    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_SORT_TEST_KNOBS, 1) == -10001               # only the result-preserving knobs exist in the release library
+    assert L.bvh_ctx_set_option(ctx.handle, 17, 0) == -10001 and L.bvh_ctx_get_option(ctx.handle, 17, C.byref(v)) == -10001
+    # a stray environment variable must not change anything (round 2's library read BVH_HPLOC_MODE / BVH_LBVH_MODE / BVH_SORT_DEBUG)
+    tris = pkg.meshgen.uniform(40_000, 5)
+    ref = pkg.HPLOC().build(ctx, tris).checksum()
+    os.environ["BVH_HPLOC_MODE"] = "block"; os.environ["BVH_SORT_DEBUG"] = "3"
+    try:
+        ctx.set_profiling(2)
+        assert pkg.HPLOC().build(ctx, tris).checksum() == ref
+        assert "k_hploc" in ctx.kernel_times() and "k_hploc_block" not in ctx.kernel_times()     # 40 k: the one-launch kernel, whatever the environment says
+    finally:
+        del os.environ["BVH_HPLOC_MODE"], os.environ["BVH_SORT_DEBUG"]; ctx.set_profiling(0)
+    with ctx.options(hploc="block"):
+        ctx.set_profiling(2)
+        assert pkg.HPLOC().build(ctx, tris).checksum() == ref and "k_hploc_block" in ctx.kernel_times()
+        ctx.set_profiling(0)
+    assert ctx.get_option("hploc") == 0
+
+
+def test_timings_sampled_flag(pkg, ctx):
+    """bvh_ctx_set_kernel_sampling(k): k - 1 of k builds are un-instrumented and say so (sampled = 0, ms_* = 0)"""
+    tris = pkg.meshgen.uniform(30_000, 6)
+    ctx.set_kernel_sampling(3); ctx.set_profiling(1)
+    flags = []
+    for _ in range(6):
+        b = pkg.SinglePassLbvh().build(ctx, tris)
+        flags.append((b.timings.sampled, b.timings.ms_total > 0))
+    ctx.set_kernel_sampling(1); ctx.set_profiling(0)
+    assert flags == [(1, True), (0, False), (0, False)] * 2
+    assert pkg.SinglePassLbvh().build(ctx, tris).timings.sampled == 0                              # profiling off
+
+
+def test_batch_allgather_is_timed_outside_the_group(pkg):
+    """the events around the RCCL all-gather were recorded inside ncclGroupStart/End and measured nothing for n_dev > 1"""
+    import torch
+    nd = torch.cuda.device_count()
+    mg = pkg.meshgen
+    meshes = [mg.uniform(20_000, 50 + m) for m in range(max(nd, 2))]
+    L = pkg.lib()
+    h = C.c_void_p(); devs = (C.c_int * nd)(*range(nd))
+    assert L.bvh_batch_create(nd, devs, C.byref(h)) == 0
+    try:
+        ptrs = (C.c_void_p * len(meshes))(*[m.ctypes.data for m in meshes]); ns = (C.c_uint32 * len(meshes))(*[len(m) for m in meshes])
+        roots = (C.c_float * (6 * len(meshes)))()
+        rep = pkg.BatchReport(); rep.root_aabbs = C.cast(roots, C.POINTER(C.c_float))
+        assert L.bvh_batch_build(h, 3, ptrs, ns, len(meshes), C.byref(rep)) == 0
+        assert rep.allgather_us > 0.5, rep.allgather_us            # a collective (or its one-rank copy) takes microseconds, not an empty interval
+    finally:
+        L.bvh_batch_destroy(h)
