@@ -531,6 +531,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ u32 s_npub, s_nready, s_qbase;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
     __shared__ u64 s_nn[NT / WAVE][WAVE];            // per wave: nearest-neighbour keys of the PLOC rounds
+#ifdef ABL_LDS_PAD       // in-situ probe: fewer workgroups per CU (is the kernel bound by latency x occupancy?)
+    __shared__ u32 s_pad[ABL_LDS_PAD / 4];
+    if (threadIdx.x == 0 && n == 0xFFFFFFFFu) s_pad[blockIdx.x % (ABL_LDS_PAD / 4)] = 1u;
+#endif
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
@@ -775,7 +779,8 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
 
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn);
 
-    // hand-over
+    // hand-over.  (Reading the parent's word before the rounds, so that the coherent round trip hides under them, changes nothing: k_hploc_ext at 10 M
+    // 0.220 vs 0.217 ms, round 3.)
     bool fast = false; u32 nL = 0, nR = 0; u64 mine = 0;
     if (owner && q != INV) {
         mine = q == R ? dep_word(1u, L, 0u) : dep_word(1u, 0u, R);
