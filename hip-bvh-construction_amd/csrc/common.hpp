@@ -131,6 +131,14 @@ template <int K> __device__ __forceinline__ float row_shl(float v) {
 template <int K> __device__ __forceinline__ Box row_shl(const Box& b) {
     return { row_shl<K>(b.lx), row_shl<K>(b.ly), row_shl<K>(b.lz), row_shl<K>(b.hx), row_shl<K>(b.hy), row_shl<K>(b.hz) };
 }
+// whole-wave shift by one lane (DPP wave_shl:1): lane i <- lane i + 1, lane 63 reads 0
+__device__ __forceinline__ float dpp_shl1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+__device__ __forceinline__ Box box_shl1(const Box& b) { return { dpp_shl1(b.lx), dpp_shl1(b.ly), dpp_shl1(b.lz), dpp_shl1(b.hx), dpp_shl1(b.hy), dpp_shl1(b.hz) }; }
+__device__ __forceinline__ Box shfl_box(const Box& b, int src) {
+    return { __shfl(b.lx, src), __shfl(b.ly, src), __shfl(b.lz, src), __shfl(b.hx, src), __shfl(b.hy, src), __shfl(b.hz, src) };
+}
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 // Aabb::area (src/Common.h:361-365) of two boxes at once (packed f32): 2 * (xy + xz + yz), same association, no contraction; x + x == 2 * x exactly
 __device__ __forceinline__ v2f_t area_pair(v2f_t lx, v2f_t ly, v2f_t lz, v2f_t hx, v2f_t hy, v2f_t hz) {

@@ -57,13 +57,6 @@ constexpr u32 HP_HALF = 16;        // WarpSize/2 of the reference's wave32 (src/
 constexpr int HP_RADIUS = 8;       // PlocRadius, src/Common.h:595
 
 __device__ __forceinline__ int clz64(u64 v) { return v ? __clzll((long long)v) : 64; }
-__device__ __forceinline__ float dpp_shl1(float v) {   // lane i <- lane i+1 (whole wave; DPP wave_shl:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, true));   // bound_ctrl: lane 63 reads 0
-}
-__device__ __forceinline__ Box box_shl1(const Box& b) { return { dpp_shl1(b.lx), dpp_shl1(b.ly), dpp_shl1(b.lz), dpp_shl1(b.hx), dpp_shl1(b.hy), dpp_shl1(b.hz) }; }
-__device__ __forceinline__ Box shfl_box(const Box& b, int src) {
-    return { __shfl(b.lx, src), __shfl(b.ly, src), __shfl(b.lz, src), __shfl(b.hx, src), __shfl(b.hy, src), __shfl(b.hz, src) };
-}
 // push semantics: lane l's value lands in lane dst(l)
 __device__ __forceinline__ u32 push_u32(int dst, u32 v) { return (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)v); }
 __device__ __forceinline__ float push_f32(int dst, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v))); }
@@ -794,7 +787,12 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     const bool hfast = __shfl((int)fast, hbase) != 0;
     // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated — unless they stay in registers
     if (have && !w.final_ && !hfast && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);
+#ifdef ABL_EXT_NOCLIMB   // in-situ probe: every queue item runs its first task only (how much of k_hploc_ext is throughput, how much the climb?)
+    if (owner) { ready = false; cw.side = 0; }
+    if (owner && false) {
+#else
     if (owner) {
+#endif
         ready = false; cw.side = 0;
         if (q != INV) {
             if (fast) { cw.side = (q == R) ? 1 : 2; L = nL; R = nR; ready = true; }

@@ -90,6 +90,55 @@ __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
     return base + inc - v;
 }
 
+// The last rounds of the single-workgroup tail: once <= 64 clusters are left they sit one per lane in ONE wave and the remaining ~19 rounds (the list
+// shrinks ~20 % per round) run without a barrier — a round of the workgroup loop above costs ~2.7 us (four barriers, a block scan, 16 neighbour boxes
+// read from LDS per cluster), a wave round ~0.8 us.  Same rule: nearest neighbour within +-8 positions under {area bits, position}, mutual pairs merge,
+// the lower position owns the node, node index = c - 2 - (merges at lower positions), survivors keep their order (SinglePassPloc :131-205).
+// Neighbour boxes come through a DPP wave_shl:1 chain; every pair is evaluated once and minimised into both ends' key words (LDS atomics; a wave's
+// LDS operations execute in order); compaction goes through the LDS list (write to the rank, read the own position back).
+// Round 3, measured at Sponza-262 144: tail launch 75 -> 58 us, emit 0.383 -> 0.366 ms.  (Also tried: late launches with LDS for 4096 clusters so that the
+// single-workgroup tail starts below 4096 instead of 1024 — the ten 8-us launches it replaces become six in-LDS rounds of ~5 us on ONE CU plus more empty
+// launches at the end of the batch: 0.386 ms, dropped.)
+__device__ __forceinline__ void ploc_tail_wave(PlocLds& s, u32 c, bvh2_node* __restrict__ nodes, int lane) {
+    u32 id = (u32)lane < c ? s.id[lane] : INV;
+    Box b = (u32)lane < c ? lds_box(s, lane) : box_empty();
+    const u64 lt = lanemask_lt();
+    while (c > 1u) {
+        s.nn[lane] = ~0ull; s.nn[lane + WAVE] = ~0ull;     // (pairs reach at most 8 positions beyond the last lane)
+        compiler_fence();
+        Box nb = b;
+#pragma unroll
+        for (int r = 1; r <= PL_RADIUS; ++r) {
+            nb = box_shl1(nb);                             // box of position lane + r
+            if ((u32)(lane + r) < c) {
+                const unsigned long long key = (unsigned long long)__float_as_uint(box_area(box_union(nb, b))) << 32;
+                atomicMin(reinterpret_cast<unsigned long long*>(s.nn + lane + r), key | (u32)lane);
+                atomicMin(reinterpret_cast<unsigned long long*>(s.nn + lane), key | (u32)(lane + r));
+            }
+        }
+        compiler_fence();
+        const bool in = (u32)lane < c;
+        const int nbr = in ? (int)(u32)s.nn[lane] : lane;
+        const bool mutual = in && (u32)__shfl(nbr, nbr) == (u32)lane;
+        const bool merge = mutual && lane < nbr, absorbed = mutual && lane > nbr;
+        const u32 id_nb = (u32)__shfl((int)id, nbr);
+        const Box bn = shfl_box(b, nbr);
+        const u64 mm = __ballot(merge);
+        if (merge) {
+            b = box_union(b, bn);
+            const u32 at = c - 2u - (u32)__popcll(mm & lt);                     // :168
+            node_store_plain(nodes + at, id, id_nb, b);
+            id = at;
+        }
+        const bool keep = in && !absorbed;
+        const u64 km = __ballot(keep);
+        if (keep) lds_set(s, (int)__popcll(km & lt), id, b);
+        c = (u32)__popcll(km);
+        id = (u32)lane < c ? s.id[lane] : INV;
+        b = (u32)lane < c ? lds_box(s, lane) : box_empty();
+    }
+}
+
 // counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
 // FIRST: the build's first iteration reads the clusters straight from the sorted values and the primitive boxes and writes the
 // PrimRef leaves on the way — SetupClusters (:39-55) fused: the initial cluster list (32 B written + 32 B read per primitive) never exists.
@@ -126,6 +175,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         __syncthreads();
         u32 c = C;
         while (c > 1) {
+            if (c <= (u32)WAVE) { if (tid < WAVE) ploc_tail_wave(s, c, nodes, tid); break; }         // (block-uniform; the list in LDS is complete: barrier above / at the loop's end)
             for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = (u64)nearest(s, k, 0, (int)c);   // :131-148, range clipped to [0,c)
             __syncthreads();
             // each thread owns PL_CPT consecutive list positions
