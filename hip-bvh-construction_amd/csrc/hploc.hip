@@ -595,6 +595,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             m_range[k] = ext ? M_EXT : 0u;
             if (!ext && (u32)(hi - lo + 1) > HP_HALF) {
                 m_range[k] = (u32)(lo - (int)g0) | ((u32)(hi - (int)g0) << 16);
+#ifdef ABL_SKIP_ABOVE    // in-situ probe: local nodes of more than ABL_SKIP_ABOVE leaves are not run at all (what would the tile kernel cost without its thin upper levels?)
+                if ((u32)(hi - lo + 1) > (u32)ABL_SKIP_ABOVE) continue;
+#endif
                 my_lv[i] = NLEV - 1 - c0;
                 my_pos[i] = atomicAdd(&s_cnt[my_lv[i]], 1u);
             }
@@ -739,6 +742,9 @@ template <typename K>
 __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, ExtCarry& cw, const K* __restrict__ skeys,
                                          const bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
+#ifdef ABL_EXT_STOP_ABOVE   // in-situ probe: nodes of more than n / ABL_EXT_STOP_ABOVE leaves are not run (how much of k_hploc_ext is the chain at the top of the tree?)
+    if (ready && (R - L + 1u) > (ni + 1u) / (u32)ABL_EXT_STOP_ABOVE) { ready = false; cw.side = 0; st_agent(dep + pc, 0ull); }
+#endif
     const bool have = __shfl((int)ready, hbase) != 0;
     const u32 tL = (u32)__shfl((int)L, hbase), tR = (u32)__shfl((int)R, hbase), tP = (u32)__shfl((int)pc, hbase);
     const int side = __shfl(cw.side, hbase);
@@ -891,6 +897,9 @@ size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SU
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared) {
     if (!heads_cleared) (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
+#ifdef ABL_EXT_STOP_ABOVE
+    (void)hipMemsetAsync(sc.dep, 0, (size_t)n * sizeof(u64), s);     // (the probe leaves the dependency words of the unprocessed top nodes dirty)
+#endif
     int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
     const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);

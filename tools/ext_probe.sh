@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-for v in abl noclimb; do
+for v in "$@"; do
 echo "== $v"
 BVH_MI355X_LIB=/root/repo/build/variants/libbvh_$v.so timeout 120 python - <<'PY'
 import os, sys
