@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""profiles/issue_counters.json from a rocprofv3 --pmc pass (SQ counters only) of bench.py: per kernel the per-launch averages that bench.py turns into
+roofline.issue = {valu_busy_frac, lds_busy_frac, waves_parked_frac}:
+    valu_busy_frac = SQ_INSTS_VALU x cycles_per_valu_inst / (simds x SQ_BUSY_CYCLES / shader_engines)
+    lds_busy_frac  = SQ_INSTS_LDS  x cycles_per_lds_inst  / (cus   x SQ_BUSY_CYCLES / shader_engines)
+cycles_per_*_inst: the instruction mix of the kernel's PLOC round (profiles/r03_hploc_bound.md section 3, round-3 loop) priced with the measured
+per-kind costs of profiles/r03_ubench_issue.md — VALU: (42 DPP moves + 54 min/max + 8 compares) x 4.1 + 36 packed x 4.3 + 16 moves x 2.2 + ~40 others x 3.3
+over ~196 = 3.8 cycles; LDS (round-3 tile kernel): 148 LDS-pipe cycles over 32 instructions = 4.6 cycles.
+Usage: tools/issue_counters.py <results.db> <n_tris> [out.json]"""
+import json
+import sqlite3
+import sys
+
+CONST = {"k_hploc_block": (3.8, 4.6), "k_hploc_ext": (3.8, 5.9), "k_hploc": (3.8, 5.9)}     # (cycles per VALU instruction, per LDS instruction)
+WANT = ("SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1]); n = int(sys.argv[2])
+    cols = [d[1] for d in db.execute("pragma table_info('counters_collection')")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    rows = db.execute(f"select {name_col}, counter_name, avg(value), count(*) from counters_collection group by {name_col}, counter_name").fetchall()
+    out = {}
+    for kname, counter, avg, cnt in rows:
+        k = kname.split("(")[0].replace("void ", "").replace("bvh::", "").split("<")[0]
+        if k not in CONST or counter not in WANT:
+            continue
+        e = out.setdefault(f"{k}@{n}", {"shader_engines": 32, "simds": 1024, "cus": 256, "cycles_per_valu_inst": CONST[k][0], "cycles_per_lds_inst": CONST[k][1],
+                                          "launches_averaged": cnt, "source": "rocprofv3 --pmc " + " ".join(WANT) + " -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events"})
+        e[counter] = avg
+    for k, e in out.items():
+        cyc = e["SQ_BUSY_CYCLES"] / 32
+        print(k, "valu_busy %.3f  lds_busy %.3f  parked %.3f" % (e["SQ_INSTS_VALU"] * e["cycles_per_valu_inst"] / (1024 * cyc), e["SQ_INSTS_LDS"] * e["cycles_per_lds_inst"] / (256 * cyc), e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]))
+    if len(sys.argv) > 3:
+        json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
