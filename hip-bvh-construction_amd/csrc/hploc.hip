@@ -118,6 +118,10 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
     return w;
 }
 
+#ifndef HP_NN_SCALAR
+#define HP_NN_SCALAR 1     // 1 (default since round 3): nn_search evaluates one candidate per step with scalar f32 operations — fewer live registers (the tile kernel
+                           //    no longer spills at 7 waves per SIMD) and each pair's atomics leave as soon as its area exists: tile kernel 0.714 -> 0.67 ms; 0: two per step, packed f32
+#endif
 #ifndef HP_NN_LDS
 #define HP_NN_LDS 1        // 1: neighbour selection by LDS atomic minima (default); 0: round 1's alternative (two running minima in registers, the left
 #endif                     //    candidates' areas through ds_bpermute; needs more registers: spills at 7 waves per SIMD) for A/B builds
@@ -140,6 +144,28 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
     u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
     const int la = lane << 2;
 #endif
+#if HP_NN_SCALAR && HP_NN_LDS >= 1 && !defined(ABL_NO_ATOMIC)
+    // one candidate per step, scalar f32 (a packed f32 operation costs what two scalar ones do on gfx950 — profiles/r03_ubench_issue.md — and the
+    // two-candidate form keeps twelve more registers alive): the same operations in the same association
+    Box nb = b;
+#pragma unroll
+    for (int rr = 1; rr <= HP_RADIUS; ++rr) {
+#ifndef ABL_NO_DPPMOV
+        nb = box_shl1(nb);                                                       // box of slot + rr
+#endif
+        const float ex = fmaxf(nb.hx, b.hx) - fminf(nb.lx, b.lx), ey = fmaxf(nb.hy, b.hy) - fminf(nb.ly, b.ly), ez = fmaxf(nb.hz, b.hz) - fminf(nb.lz, b.lz);
+        const float half_area = ex * ey + ex * ez + ey * ez;                     // Aabb::area (:361-365): 2 * (xy + xz + yz)
+        const u32 ab = __float_as_uint(half_area + half_area);                   // (x + x == 2 * x exactly)
+        if (act && (u32)(slot + rr) < cnt) {                                     // both ends are clusters of this task
+            atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
+#if HP_NN_LDS == 2
+            if (ab < abR) { abR = ab; idR = slot + rr; }
+#else
+            atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
+#endif
+        }
+    }
+#else
     Box nb = b;
     typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -181,6 +207,7 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
 #endif
         }
     }
+#endif
     int probe = 0;
 #ifdef ABL_EXTRA_BPERM   // 8 more LDS crossbar operations per round
 #pragma unroll
@@ -205,6 +232,42 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
     return ((abL <= abR) ? idL : idR) | (probe == 0x7fffabcd ? 64 : 0);
 #endif
 }
+
+// The same search for the tile kernel's INTERLEAVED lane layout (HPB_IL): lanes 0..15 of a half hold the task's even slots, lanes 16..31 the odd ones, and
+// every lane also holds o = the box of slot + 1 (read from the LDS list together with its own record).  The box of slot + r is then a 16-lane ROW shift of
+// b (r even: by r / 2) or of o (r odd: by (r - 1) / 2; r = 1: o itself) — a DPP operand of the union's v_min / v_max, no data movement: the 48 v_mov_b32_dpp of
+// the wave_shl chain are gone.  A shift that leaves the row reads 0; such a pair has slot + r >= 32 >= cnt and is masked.  nnh: the half's 32 (+ 8) key words, by slot.
+#ifndef HP_IL_MASKED
+#define HP_IL_MASKED 0
+#endif
+#if HP_IL_MASKED
+#define HP_IL_ATOMICS(RR) const u32 ab = __float_as_uint(half_area + half_area); \
+        if (act && (u32)(slot + (RR)) < cnt) { \
+            atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot + (RR)), ((unsigned long long)ab << 32) | (u32)slot); \
+            atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot), ((unsigned long long)ab << 32) | (u32)(slot + (RR))); }
+#else
+#define HP_IL_ATOMICS(RR) const u32 ab = (act && (u32)(slot + (RR)) < cnt) ? __float_as_uint(half_area + half_area) : 0xFFFFFFFFu; \
+        atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot + (RR)), ((unsigned long long)ab << 32) | (u32)slot); \
+        atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot), ((unsigned long long)ab << 32) | (u32)(slot + (RR)));
+#endif
+#define HP_IL_CAND(RR, SRC, K) { \
+        const Box n_ = (K) == 0 ? (SRC) : row_shl<((K) == 0 ? 1 : (K))>(SRC); \
+        const float ex = fmaxf(n_.hx, b.hx) - fminf(n_.lx, b.lx), ey = fmaxf(n_.hy, b.hy) - fminf(n_.ly, b.ly), ez = fmaxf(n_.hz, b.hz) - fminf(n_.lz, b.lz); \
+        const float half_area = ex * ey + ex * ez + ey * ez; \
+        /* no branch around the atomics: a pair that does not exist sends the key's high word as all ones, which never wins a minimum (and an address */ \
+        /* beyond the half's words is only ever "minimised" with that).  With a branch the compiler sinks the union into it, and the DPP operand */ \
+        /* cannot follow (cross-lane reads need the full EXEC mask): the row shifts would stay separate v_mov_b32_dpp */ \
+        HP_IL_ATOMICS(RR) }
+__device__ __forceinline__ int nn_search_il(const Box& b, const Box& o, bool act, u32 cnt, int slot, u64* nnh) {
+    nnh[slot] = ~0ull;
+    compiler_fence();
+    HP_IL_CAND(1, o, 0) HP_IL_CAND(2, b, 1) HP_IL_CAND(3, o, 1) HP_IL_CAND(4, b, 2)
+    HP_IL_CAND(5, o, 2) HP_IL_CAND(6, b, 3) HP_IL_CAND(7, o, 3) HP_IL_CAND(8, b, 4)
+    compiler_fence();
+    return (int)(u32)nnh[slot];
+}
+#undef HP_IL_CAND
+#undef HP_IL_ATOMICS
 
 // PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
 // registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
@@ -302,22 +365,29 @@ struct TileList {            // k_hploc_block: id / rep tile-relative in 16 bits
     __device__ __forceinline__ void store(u32 pos, Tag t, const Box& b) const {
         ir[pos] = t; b0[pos] = make_float2(b.lx, b.ly); b1[pos] = make_float2(b.lz, b.hx); b2[pos] = make_float2(b.hy, b.hz);
     }
+    __device__ __forceinline__ Box load_box(u32 pos) const {
+        const float2 q0 = b0[pos], q1 = b1[pos], q2 = b2[pos];
+        return { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
+    }
     __device__ __forceinline__ Tag tag_at(u32 pos) const { return ir[pos]; }
     __device__ __forceinline__ void invalidate(u32 pos) const { ir[pos] = 0xFFFFFFFFu; }
 };
 // One task per 32-lane half.  In: have / final_ (uniform per half), cnt, and the lane's cluster (tag, b; invalid beyond cnt) as loaded from the list.
 // Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
-template <bool AGENT, typename List>
+// IL: interleaved lane layout (nn_search_il): slot is NOT lane & 31; below = the half's lanes that hold lower slots; o_in = box of slot + 1.
+template <bool AGENT, bool IL, typename List>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
-                                                const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn) {
+                                                const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
+                                                u32 below = 0u, Box o_in = Box()) {
     typename List::Tag tag = tag_io;
     u32 cnt = cnt_io;
-    Box b = b_io;
+    Box b = b_io, o = o_in;
+    if (!IL) below = (1u << slot) - 1u;
     const u32 threshold = final_ ? 1u : HP_HALF;
     bool moved = nl >= cnt;                           // every slot already sits at base + slot
     while (__ballot(have && cnt > threshold)) {
         const bool act = have && cnt > threshold;
-        const u32 nbr = (u32)nn_search(b, act, cnt, lane, slot, nn) & 31u;
+        const u32 nbr = (u32)(IL ? nn_search_il(b, o, act, cnt, slot, nn + hbase) : nn_search(b, act, cnt, lane, slot, nn)) & 31u;
         // mergeClusters (:126-190): the neighbour's choice (low word of its key) and its record, read in one go
         const bool in = act && (u32)slot < cnt;
         const u32 pn = nbr < nl ? base + nbr : rbase + nbr;
@@ -364,12 +434,13 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
         const bool keep = in && !absorbed;
         const u32 kh = (u32)(__ballot(keep) >> hbase);
         const u32 newcnt = (u32)__popc(kh);
-        if (keep) list.store(base + (u32)__popc(kh & ((1u << slot) - 1u)), tag, b);
-        typename List::Tag t2; Box b2;
+        if (keep) list.store(base + (u32)__popc(kh & below), tag, b);
+        typename List::Tag t2; Box b2, o2 = o;
         list.load(base + (u32)slot < lim ? base + (u32)slot : lim, t2, b2);
+        if (IL) o2 = list.load_box(base + (u32)slot + 1u < lim ? base + (u32)slot + 1u : lim);
         if (act) {
             cnt = newcnt; nl = 32u; moved = true;
-            b = b2; tag = (u32)slot < newcnt ? t2 : List::invalid_tag();
+            b = b2; o = o2; tag = (u32)slot < newcnt ? t2 : List::invalid_tag();
         }
 #ifdef ABL_EXTRA_TRIP    // in-situ probe: one more DEPENDENT LDS round trip per round (a 4-byte read whose address depends on the read-back, result waited for)
         { u32 x = (u32)nn[(__float_as_uint(b.lx) >> 29) + (u32)(lane & 56)];
@@ -511,7 +582,24 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
     constexpr int NLEV = KeyBits<K>::value;          // hierarchy levels = bits of the augmented key (64 / 96)
     constexpr int KM = 18;                           // key margin: the hand-over probes up to 17 leaves beyond the tile's rims (small children of external
+#ifndef HPB_IL
+#define HPB_IL 0         // 1: interleaved lane layout of the tile kernel's rounds (nn_search_il: the row shifts become DPP operands of v_min / v_max, 48 fewer VALU
+                         //    instructions per round) — measured SLOWER, 0.72 vs 0.66 ms (round 3): the six more live registers (box of slot + 1) spill at 7 waves per SIMD
+                         //    and cost three more LDS reads per round; the wave_shl chain's moves are off the critical path anyway.  Kept for A/B.
+#endif
+#ifndef HPB_LEAN
+#define HPB_LEAN 0       // 1: 20.3 KB of LDS instead of 22.9 (eight workgroups per CU): the key window shares its storage with the rounds' key words and is
+#endif                   //    re-read for the hand-over; level counters sized for the key type
+#if HPB_LEAN
+    constexpr int NLV = NLEV;
+    constexpr size_t KN_BYTES = sizeof(K) * (T + 2 * KM) > sizeof(u64) * (NT + 8) ? sizeof(K) * (T + 2 * KM) : sizeof(u64) * (NT + 8);
+    __shared__ u64 s_kn[(KN_BYTES + 7) / 8];
+    K* const s_key = reinterpret_cast<K*>(s_kn);
+    u64 (* const s_nn)[WAVE] = reinterpret_cast<u64 (*)[WAVE]>(s_kn);
+#else
+    constexpr int NLV = 128;
     __shared__ K s_key[T + 2 * KM];                  // nodes) — with the margin in LDS none of them is a dependent global load; positions g0-KM .. g0+T+KM-1
+#endif
     // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
     // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
     __shared__ u32 e_ir[T];                          // id | rep << 16, tile-relative (TileList)
@@ -520,10 +608,13 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     float2* const e_b0 = e_bx; float2* const e_b1 = e_bx + T + 1; float2* const e_b2 = e_bx + 2 * T + 2;
     __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
-    __shared__ u32 s_cnt[128], s_off[128];
+    __shared__ u32 s_cnt[NLV], s_off[NLV];
     __shared__ u32 s_npub, s_nready, s_qbase;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
-    __shared__ u64 s_nn[NT / WAVE][WAVE];            // per wave: nearest-neighbour keys of the PLOC rounds
+#if !HPB_LEAN
+    __shared__ u64 s_nnf[NT + 8];                    // per wave: 64 nearest-neighbour key words of the PLOC rounds (+ 8: nn_search_il's unmasked atomics of the last
+    u64 (* const s_nn)[WAVE] = reinterpret_cast<u64 (*)[WAVE]>(s_nnf);   //   wave's highest slots reach 8 words further; they carry all-ones keys and change nothing)
+#endif
 #ifdef ABL_LDS_PAD       // in-situ probe: fewer workgroups per CU (is the kernel bound by latency x occupancy?)
     __shared__ u32 s_pad[ABL_LDS_PAD / 4];
     if (threadIdx.x == 0 && n == 0xFFFFFFFFu) s_pad[blockIdx.x % (ABL_LDS_PAD / 4)] = 1u;
@@ -561,7 +652,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         if (__float_as_uint(acc) == 0x7fffabcdu) e_ir[0] = 0u; }
 #endif
     for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
-    if (tid < 128) s_cnt[tid] = 0u;
+    if (tid < NLV) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; }
     __syncthreads();
     if (dbg == 1) return;
@@ -605,10 +696,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
     __syncthreads();
     if (tid < 64) {                                  // exclusive scan of the (<= 128) level counts, two per lane
-        const u32 v0 = s_cnt[2 * tid], v1 = s_cnt[2 * tid + 1]; u32 incl = v0 + v1;
+        const u32 v0 = 2 * tid < NLV ? s_cnt[2 * tid] : 0u, v1 = 2 * tid + 1 < NLV ? s_cnt[2 * tid + 1] : 0u; u32 incl = v0 + v1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
-        s_off[2 * tid] = incl - v0 - v1; s_off[2 * tid + 1] = incl - v1;
+        if (2 * tid + 1 < NLV) { s_off[2 * tid] = incl - v0 - v1; s_off[2 * tid + 1] = incl - v1; }
     }
     __syncthreads();
 #pragma unroll
@@ -639,16 +730,29 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb >> 16);
             u32 cnt = nl + nr;
             const u32 rbase = P + 1u - nl;
-            const u32 sp = (u32)slot < nl ? L + (u32)slot : rbase + (u32)slot;
+#if HPB_IL
+            const int ts = ((lane & 15) << 1) | ((lane >> 4) & 1);                               // the task slot this lane holds (interleaved layout: nn_search_il)
+            const u32 below = ((1u << ((lane & 15) + ((lane >> 4) & 1))) - 1u) | (((1u << (lane & 15)) - 1u) << 16);
+#else
+            const int ts = slot; const u32 below = 0u;
+#endif
+            const u32 sp = (u32)ts < nl ? L + (u32)ts : rbase + (u32)ts;
+            const u32 sp1 = (u32)ts + 1u < nl ? L + (u32)ts + 1u : rbase + (u32)ts + 1u;
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
-            if (!(have && (u32)slot < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, slot, hbase, s_nn[wave]);
-            if (have && (u32)slot >= cnt && slot < 16) tl.invalidate(L + (u32)slot);          // INVALID-terminated
+            const Box o = tl.load_box(sp1 < (u32)T ? sp1 : (u32)T - 1u);
+            if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
+            ploc_rounds_lds<false, HPB_IL != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below, o);
+            if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
         }
         __syncthreads();
     }
     if (dbg == 3) return;
+#if HPB_LEAN
+    // the rounds' key words overwrote the key window (every thread is past the level loop's last barrier): read it again for the hand-over
+    for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
+    __syncthreads();
+#endif
 
     // ---- hand-over, step 1 (one thread per gap): an external node adds its own contribution — which children are small, and
     // those children's far ends (child [L,p] is big iff leaf p-16 shares the prefix, child [p+1,R] iff leaf p+17 does);
