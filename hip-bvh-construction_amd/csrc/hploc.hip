@@ -258,11 +258,15 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
         /* beyond the half's words is only ever "minimised" with that).  With a branch the compiler sinks the union into it, and the DPP operand */ \
         /* cannot follow (cross-lane reads need the full EXEC mask): the row shifts would stay separate v_mov_b32_dpp */ \
         HP_IL_ATOMICS(RR) }
-__device__ __forceinline__ int nn_search_il(const Box& b, const Box& o, bool act, u32 cnt, int slot, u64* nnh) {
+// o is read from the list HERE (position opos) and used by the odd distances, which come after the even ones: the read's latency hides under four
+// candidates, and o is not alive across the merge / compaction part of the round (that is what made the first version of this layout spill).
+template <typename List>
+__device__ __forceinline__ int nn_search_il(const Box& b, const List& list, u32 opos, bool act, u32 cnt, int slot, u64* nnh) {
     nnh[slot] = ~0ull;
+    const Box o = list.load_box(opos);
     compiler_fence();
-    HP_IL_CAND(1, o, 0) HP_IL_CAND(2, b, 1) HP_IL_CAND(3, o, 1) HP_IL_CAND(4, b, 2)
-    HP_IL_CAND(5, o, 2) HP_IL_CAND(6, b, 3) HP_IL_CAND(7, o, 3) HP_IL_CAND(8, b, 4)
+    HP_IL_CAND(2, b, 1) HP_IL_CAND(4, b, 2) HP_IL_CAND(6, b, 3) HP_IL_CAND(8, b, 4)
+    HP_IL_CAND(1, o, 0) HP_IL_CAND(3, o, 1) HP_IL_CAND(5, o, 2) HP_IL_CAND(7, o, 3)
     compiler_fence();
     return (int)(u32)nnh[slot];
 }
@@ -378,16 +382,18 @@ struct TileList {            // k_hploc_block: id / rep tile-relative in 16 bits
 template <bool AGENT, bool IL, typename List>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
                                                 const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
-                                                u32 below = 0u, Box o_in = Box()) {
+                                                u32 below = 0u) {
     typename List::Tag tag = tag_io;
     u32 cnt = cnt_io;
-    Box b = b_io, o = o_in;
+    Box b = b_io;
     if (!IL) below = (1u << slot) - 1u;
     const u32 threshold = final_ ? 1u : HP_HALF;
     bool moved = nl >= cnt;                           // every slot already sits at base + slot
     while (__ballot(have && cnt > threshold)) {
         const bool act = have && cnt > threshold;
-        const u32 nbr = (u32)(IL ? nn_search_il(b, o, act, cnt, slot, nn + hbase) : nn_search(b, act, cnt, lane, slot, nn)) & 31u;
+        u32 nbr;
+        if (IL) { const u32 p1 = (u32)slot + 1u < nl ? base + (u32)slot + 1u : rbase + (u32)slot + 1u; nbr = (u32)nn_search_il(b, list, p1 < lim ? p1 : lim, act, cnt, slot, nn + hbase) & 31u; }
+        else nbr = (u32)nn_search(b, act, cnt, lane, slot, nn) & 31u;
         // mergeClusters (:126-190): the neighbour's choice (low word of its key) and its record, read in one go
         const bool in = act && (u32)slot < cnt;
         const u32 pn = nbr < nl ? base + nbr : rbase + nbr;
@@ -435,12 +441,11 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
         const u32 kh = (u32)(__ballot(keep) >> hbase);
         const u32 newcnt = (u32)__popc(kh);
         if (keep) list.store(base + (u32)__popc(kh & below), tag, b);
-        typename List::Tag t2; Box b2, o2 = o;
+        typename List::Tag t2; Box b2;
         list.load(base + (u32)slot < lim ? base + (u32)slot : lim, t2, b2);
-        if (IL) o2 = list.load_box(base + (u32)slot + 1u < lim ? base + (u32)slot + 1u : lim);
         if (act) {
             cnt = newcnt; nl = 32u; moved = true;
-            b = b2; o = o2; tag = (u32)slot < newcnt ? t2 : List::invalid_tag();
+            b = b2; tag = (u32)slot < newcnt ? t2 : List::invalid_tag();
         }
 #ifdef ABL_EXTRA_TRIP    // in-situ probe: one more DEPENDENT LDS round trip per round (a 4-byte read whose address depends on the read-back, result waited for)
         { u32 x = (u32)nn[(__float_as_uint(b.lx) >> 29) + (u32)(lane & 56)];
@@ -584,8 +589,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     constexpr int KM = 18;                           // key margin: the hand-over probes up to 17 leaves beyond the tile's rims (small children of external
 #ifndef HPB_IL
 #define HPB_IL 0         // 1: interleaved lane layout of the tile kernel's rounds (nn_search_il: the row shifts become DPP operands of v_min / v_max, 48 fewer VALU
-                         //    instructions per round) — measured SLOWER, 0.72 vs 0.66 ms (round 3): the six more live registers (box of slot + 1) spill at 7 waves per SIMD
-                         //    and cost three more LDS reads per round; the wave_shl chain's moves are off the critical path anyway.  Kept for A/B.
+                         //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
+                         //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
 #endif
 #ifndef HPB_LEAN
 #define HPB_LEAN 0       // 1: 20.3 KB of LDS instead of 22.9 (eight workgroups per CU): the key window shares its storage with the rounds' key words and is
@@ -737,12 +742,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const int ts = slot; const u32 below = 0u;
 #endif
             const u32 sp = (u32)ts < nl ? L + (u32)ts : rbase + (u32)ts;
-            const u32 sp1 = (u32)ts + 1u < nl ? L + (u32)ts + 1u : rbase + (u32)ts + 1u;
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
-            const Box o = tl.load_box(sp1 < (u32)T ? sp1 : (u32)T - 1u);
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false, HPB_IL != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below, o);
+            ploc_rounds_lds<false, HPB_IL != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
         }
         __syncthreads();
