@@ -4,14 +4,15 @@ roofline.issue = {valu_busy_frac, lds_busy_frac, waves_parked_frac}:
     valu_busy_frac = SQ_INSTS_VALU x cycles_per_valu_inst / (simds x SQ_BUSY_CYCLES / shader_engines)
     lds_busy_frac  = SQ_INSTS_LDS  x cycles_per_lds_inst  / (cus   x SQ_BUSY_CYCLES / shader_engines)
 cycles_per_*_inst: the instruction mix of the kernel's PLOC round (profiles/r03_hploc_bound.md section 3, round-3 loop) priced with the measured
-per-kind costs of profiles/r03_ubench_issue.md — VALU: (42 DPP moves + 54 min/max + 8 compares) x 4.1 + 36 packed x 4.3 + 16 moves x 2.2 + ~40 others x 3.3
-over ~196 = 3.8 cycles; LDS (round-3 tile kernel): 148 LDS-pipe cycles over 32 instructions = 4.6 cycles.
+per-kind costs of profiles/r03_ubench_issue.md — VALU (scalar neighbour search): (48 DPP moves + 54 min/max + 13 compares) x 4.1 + (72 sub/mul/add + 17 moves) x 2.2
++ ~40 others x 3.3 over ~244 = 3.3 cycles; LDS (round-3 tile kernel): 148 LDS-pipe cycles over 32 instructions = 4.6 cycles.  These are saturated-pipe prices:
+the in-situ probes of profiles/r03_hploc_bound.md show the VALUs are not the limiter, so valu_busy_frac is an upper estimate.
 Usage: tools/issue_counters.py <results.db> <n_tris> [out.json]"""
 import json
 import sqlite3
 import sys
 
-CONST = {"k_hploc_block": (3.8, 4.6), "k_hploc_ext": (3.8, 5.9), "k_hploc": (3.8, 5.9)}     # (cycles per VALU instruction, per LDS instruction)
+CONST = {"k_hploc_block": (3.3, 4.6), "k_hploc_ext": (3.3, 5.9), "k_hploc": (3.3, 5.9)}     # (cycles per VALU instruction, per LDS instruction)
 WANT = ("SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
 
 
