@@ -505,8 +505,11 @@ __device__ __forceinline__ void async_climb(bool ready, u32 pc, u32 L, u32 R, co
 }
 
 // Small inputs: one launch.  Phase 1: range of every gap from the keys; big nodes enter the dependency protocol.  Phase 2: climb.
+#ifndef HPA_OCC
+#define HPA_OCC 7        // waves per SIMD of the one-launch kernel (68 VGPRs)
+#endif
 template <typename K>
-__global__ __launch_bounds__(HP_BLOCK) void k_hploc(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
+__global__ __launch_bounds__(HP_BLOCK, HPA_OCC) void k_hploc(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* leaves,
                                                     bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 n, int dbg) {
     const int lane = threadIdx.x & (WAVE - 1);
