@@ -252,11 +252,23 @@ int bvh_ctx_set_option(bvh_ctx* c, bvh_option option, int64_t value) {
     c->sort.test_knobs = (int)c->options[BVH_OPT_SORT_TEST_KNOBS];
     return 0;
 }
+#ifdef BVH_ABLATION   // measurement build only: raw reads of the HPLOC queue buffers (the upper half of queue_rng doubles as a trace buffer: tools/ext_trace.py)
+extern "C" int bvh_debug_read_queue(bvh_ctx* c, int which, size_t off_words, void* dst, size_t nwords) {
+    if (!c || !dst) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return BVH_E_INTERNAL;
+    if (which == 0) { if (hipMemcpy(dst, c->hploc.queue_count + off_words, nwords * 4, hipMemcpyDeviceToHost) != hipSuccess) return BVH_E_INTERNAL; }
+    else if (which == 1) { if (off_words + nwords > c->hploc.queue_capacity || hipMemcpy(dst, c->hploc.queue_rng + off_words, nwords * 8, hipMemcpyDeviceToHost) != hipSuccess) return BVH_E_INTERNAL; }
+    else if (which == 2) { *(uint64_t*)dst = c->hploc.queue_capacity; }
+    else return BVH_E_INVALID_ARG;
+    return 0;
+}
+#endif
 int bvh_ctx_get_option(const bvh_ctx* c, bvh_option option, int64_t* value_out) {
 #ifdef BVH_ABLATION   // measurement build only: option 1000 = merge tasks the HPLOC tile kernel ran in the last build (tools/measure_task_share.py)
-    if (c && value_out && (int)option == 1000) {
+    if (c && value_out && (int)option >= 1000 && (int)option < 1000 + 2046) {      // 1001..: the other measurement words of sub-queue 0's padded head (ABL_EXT_TIMING)
         u32 v = 0; Bind b(c->device);
-        if (!c->hploc.queue_count || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->hploc.queue_count + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) return BVH_E_INTERNAL;
+        if (!c->hploc.queue_count || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->hploc.queue_count + 2 + ((int)option - 1000), 4, hipMemcpyDeviceToHost) != hipSuccess) return BVH_E_INTERNAL;
         *value_out = v; return 0;
     }
 #endif
