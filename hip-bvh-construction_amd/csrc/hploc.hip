@@ -278,7 +278,7 @@ __device__ __forceinline__ int nn_search_il(const Box& b, const List& list, u32 
 // read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
 // nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (nn_search)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// hook: called at the end of every round (k_hploc_ext's look-ahead consumes a coherent load it issued before the rounds there)
+// hook: called at the end of every round (the measurement builds count rounds there; tools/probes/hploc_ext_lookahead_wide.patch consumed an early load)
 template <bool AGENT = true, typename Hook = NoHook>
 __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, u64* nn, Hook hook = Hook()) {
         const bool have = w.have, final_ = w.final_;
@@ -969,150 +969,8 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
 #endif
 }
 
-// ---- ext_pass with look-ahead (round 3, HPX_LOOKAHEAD) ------------------------------------------------------------------------------------
-// k_hploc_ext is a dependency chain (its time does not move between 3 and 6 waves per SIMD): what counts is the latency of ONE level of the climb, and
-// in ext_pass that is the rounds plus two exposed coherent round trips — the parent's dependency word after the rounds, then the sibling's records.
-// Here the address path runs one level ahead of the rounds.  The owner knows its parent q when the task starts (from the previous level's look-ahead) and
-// reads dep[q] BEFORE the rounds; the answer is consumed after the first round (hook of ploc_rounds).  If the count already stands at 2 every other
-// contribution is in — nobody else will touch the word again — so this task will complete the parent whenever it ends: the word is reset at once, the parent's
-// range is the sum, the sibling's records (or leaves) and the four keys that decide the grandparent are loaded while the remaining rounds run, and the next
-// pass starts with its whole work list in registers.  A sibling that is still running (count < 2 at the early read) falls back to ext_pass's protocol.
-struct ExtAhead { u32 q; bool q_known, sib_have; u32 sid, srep; Box sb; };     // q, q_known, sib_have: owner lane; sid / srep / sb: the sibling's clusters, lanes slot < 16
-__device__ __forceinline__ bool closer_keys(u32 ka, u32 ka1, u32 a, u32 kb, u32 kb1, u32 b) {     // closer(k, a, b) on keys that are already in registers
-    return ((((u64)ka << 32) | a) ^ (((u64)ka1 << 32) | (a + 1u))) < ((((u64)kb << 32) | b) ^ (((u64)kb1 << 32) | (b + 1u)));
-}
-__device__ __forceinline__ bool closer_keys(u64 ka, u64 ka1, u32 a, u64 kb, u64 kb1, u32 b) { return plen(ka, a, ka1, a + 1u) > plen(kb, b, kb1, b + 1u); }
-template <typename K>
-__device__ __forceinline__ void ext_pass_la(bool& ready, u32& pc, u32& L, u32& R, ExtCarry& cw, ExtAhead& ah, const K* __restrict__ skeys,
-                                            const bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn EXT_TRACE_ARGS) {
-    const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
-#ifdef ABL_EXT_TRACE
-    const u64 tr0 = __builtin_amdgcn_s_memrealtime(); const u32 trL = L, trR = R; u32 tr_rounds = 0;
-#endif
-    const bool have = __shfl((int)ready, hbase) != 0;
-    const u32 tL = (u32)__shfl((int)L, hbase), tR = (u32)__shfl((int)R, hbase), tP = (u32)__shfl((int)pc, hbase);
-    const int side = __shfl(cw.side, hbase);
-    const bool pre = __shfl((int)ah.sib_have, hbase) != 0;                         // the non-carried child is in ah's registers (implies side != 0)
-    const bool owner = ready && slot == 0;
-    u32 q = INV;
-    if (owner && !(L == 0u && R == ni)) q = ah.q_known ? ah.q : parent_gap(L, R, ni, [&](u32 a, u32 b) { return closer(skeys, a, b); });
-    // the parent's word, read ahead of the rounds
-    u64 E = 0ull;
-    if (owner && q != INV) E = ld_agent(dep + q);
-
-    // work list (loadIndices :192-206): carried survivors on one side; the other side prefetched by the previous pass, or loaded now
-    const bool is_left = slot < 16;
-    const u32 s = (u32)(slot & 15);
-    const u32 c_start = is_left ? tL : tP + 1u, c_len = is_left ? (tP - tL + 1u) : (tR - tP);
-    const bool carried = have && ((side == 1 && is_left) || (side == 2 && !is_left));
-    u32 id = INV, rep = INV;
-    Box b = box_empty();
-    if (side != 0) {
-        // lanes slot < 16 hold both children's clusters; what goes to the right-hand slots 16..31: the sibling (side 1) or the carried survivors (side 2)
-        const bool sr = side == 1;
-        const u32 rid = sr ? ah.sid : cw.id, rrep = sr ? ah.srep : cw.rep;
-        const Box rb = { sr ? ah.sb.lx : cw.b.lx, sr ? ah.sb.ly : cw.b.ly, sr ? ah.sb.lz : cw.b.lz, sr ? ah.sb.hx : cw.b.hx, sr ? ah.sb.hy : cw.b.hy, sr ? ah.sb.hz : cw.b.hz };
-        const int rsrc = hbase + (int)s;
-        const u32 gid = (u32)__shfl((int)rid, rsrc), grep = (u32)__shfl((int)rrep, rsrc);
-        const Box gb = shfl_box(rb, rsrc);
-        if (is_left) { id = sr ? cw.id : ah.sid; rep = sr ? cw.rep : ah.srep; b = sr ? cw.b : ah.sb; }
-        else { id = gid; rep = grep; b = gb; }
-        if (!have || (!carried && !pre)) { id = INV; rep = INV; }
-    }
-    if (!(carried || (pre && have))) {
-        const bool leaf = have && c_len <= HP_HALF && s < c_len;
-        if (leaf) { rep = c_start + s; id = ni + rep; b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1)); }
-        if (have && c_len > HP_HALF) rec_load_agent(recs + c_start + s, id, rep, b);
-    }
-    const u32 vb = (u32)(__ballot(id != INV) >> hbase);
-    const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
-    HpWork w; w.cnt = nl + nr; w.tL = tL; w.have = have; w.final_ = have && tL == 0 && tR == ni;
-    const int src = hbase + (((u32)slot < nl) ? slot : (int)((16 + (u32)slot - nl) & 31));
-    const u32 ti = (u32)__shfl((int)id, src);
-    w.rep = (u32)__shfl((int)rep, src);
-    w.b = shfl_box(b, src);
-    w.id = ((u32)slot < w.cnt) ? ti : INV;
-
-    // the look-ahead, run once: at the end of the first round, or after the loop when no round ran
-    bool looked = false, early = false;
-    u32 nL = 0, nR = 0;
-    K ka = 0, kb = 0, kc = 0, kd = 0;                     // keys of positions nL-1, nL, nR, nR+1 (the grandparent's decision)
-    u32 sid = INV, srep = INV; Box sb = box_empty();
-    auto look = [&]() {
-#ifdef ABL_EXT_TRACE
-        ++tr_rounds;
-#endif
-        if (looked) return;
-        looked = true;
-        u32 s_start = 0, s_len = 0;
-        if (owner && q != INV && (E >> 60) == 2ull) {
-            const u64 tot = E + (q == R ? dep_word(1u, L, 0u) : dep_word(1u, 0u, R));
-            st_agent(dep + q, 0ull);
-            nL = (u32)(tot & DEP_MASK); nR = (u32)((tot >> 30) & DEP_MASK); early = true;
-            if (q == R) { s_start = R + 1u; s_len = nR - R; } else { s_start = nL; s_len = L - nL; }
-            if (!(nL == 0u && nR == ni)) {
-                if (nL != 0u) { ka = skeys[nL - 1u]; kb = skeys[nL]; }
-                if (nR != ni) { kc = skeys[nR]; kd = skeys[nR + 1u]; }
-            }
-        }
-        const bool h_early = __shfl((int)early, hbase) != 0;
-        const u32 hs = (u32)__shfl((int)s_start, hbase), hl = (u32)__shfl((int)s_len, hbase);
-        if (h_early && slot < 16) {
-            if (hl > HP_HALF) {
-                const u64* r = reinterpret_cast<const u64*>(recs + hs + (u32)slot);
-                const u64 w0 = ld_agent(r), w1 = ld_agent(r + 1), w2 = ld_agent(r + 2), w3 = ld_agent(r + 3);
-                sid = (u32)w0; srep = (u32)(w0 >> 32); sb = { lo_f(w1), hi_f(w1), lo_f(w2), hi_f(w2), lo_f(w3), hi_f(w3) };
-            } else if ((u32)slot < hl) {
-                srep = hs + (u32)slot; sid = ni + srep;
-                sb = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + srep) + 1));
-            }
-        }
-    };
-    ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, look);
-    look();
-
-    // hand-over
-    bool fast = early; u64 mine = 0;
-    if (owner && q != INV && !early) {
-        mine = q == R ? dep_word(1u, L, 0u) : dep_word(1u, 0u, R);
-        const u64 cur = ld_agent(dep + q);
-        if ((cur >> 60) == 2ull) {                    // the sibling arrived during the rounds: ext_pass's fast path (nothing prefetched)
-            const u64 tot = cur + mine;
-            st_agent(dep + q, 0ull);
-            nL = (u32)(tot & DEP_MASK); nR = (u32)((tot >> 30) & DEP_MASK); fast = true;
-        }
-    }
-    const bool hfast = __shfl((int)fast, hbase) != 0;
-    if (have && !w.final_ && !hfast && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);      // storeIndices (:208-218) unless the survivors stay in registers
-    if (owner) {
-        ready = false; cw.side = 0; ah.q_known = false; ah.sib_have = false;
-        if (q != INV) {
-            if (fast) {
-                cw.side = (q == R) ? 1 : 2; L = nL; R = nR; ready = true;
-                if (early) {
-                    ah.sib_have = true; ah.q_known = true;
-                    ah.q = (nL == 0u) ? ((nR == ni) ? INV : nR) : (nR == ni) ? nL - 1u : closer_keys(kc, kd, nR, ka, kb, nL - 1u) ? nR : nL - 1u;
-                }
-            }
-            else { drain_stores(); ready = dep_arrive(dep, q, mine, L, R); }
-            pc = q;
-        }
-    }
-    cw.id = w.id; cw.rep = w.rep; cw.b = w.b;
-    ah.sid = sid; ah.srep = srep; ah.sb = sb;
-#ifdef ABL_EXT_TRACE
-    if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, early ? 4u : fast ? 1u : ready ? 2u : 3u, tr_rounds - 1u);
-#endif
-}
-
 // External nodes (ranges crossing the tiles of k_hploc_block): the sub-queues hold the nodes whose dependencies were complete
 // when the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
-#ifndef HPX_LOOKAHEAD
-#define HPX_LOOKAHEAD 1  // 1: ext_pass_la (the parent's word, the sibling's records and the grandparent's keys are fetched one level ahead of the rounds); 0: ext_pass
-#endif
-#ifndef HPX_TICKET_SYNC
-#define HPX_TICKET_SYNC 1
-#endif
 #ifndef HPX_OCC
 #define HPX_OCC 4        // waves per SIMD of k_hploc_ext (128 VGPRs).  Round 1: 6 (80 VGPRs; emit 0.97 ms at 10 M vs 1.00 at 7, 1.13 at 8); with ext_pass's carried
                          // survivors the kernel wants more registers: k_hploc_ext at 10 M 0.226 (6) / 0.218 (5) / 0.214 (4) / 0.216 (3) / 0.251 (7) ms, 40 M 0.719 -> 0.669, 1 M unchanged
@@ -1138,7 +996,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
     u64* const trace = const_cast<u64*>(q_rng) + (size_t)q_cap * (HPQ_SUB - 1) + q_cap / 2u;      // the unused second half of the last sub-queue's storage
     u32* const trace_count = q_count + 32u + 2u;                         // word 2 of sub-queue 1's padded head
     const u32 trace_cap = (q_cap / 2u) / 4u;
-    #ifndef EXT_TRACE_NOSTART
+#ifndef EXT_TRACE_NOSTART
     if (wid == 0u && lane == 0) { const u32 at = atomicAdd(trace_count, 1u); u64* e = trace + (size_t)at * 4u; e[0] = e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = 0ull; e[3] = 0ull; }   // kernel start
 #endif
 #endif
@@ -1161,18 +1019,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         bool ready = false, dry = false, have_item = false;
         u32 pc = 0, L = 0, R = 0, tk = NO_TICKET, ipc = 0; u64 irg = 0;
         ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
-        ExtAhead ah; ah.q = INV; ah.q_known = false; ah.sib_have = false; ah.sid = INV; ah.srep = INV; ah.sb = box_empty();
         while (true) {
-#if HPX_TICKET_SYNC
-            // an idle owner takes its next item at once (two dependent round trips, ~1.5 us, during which the SIMD's other waves issue): with the two-stage
-            // pipeline below a half sits out two passes of its wave per queue item, and a third of all passes ran with one task (tools/ext_timing.py)
-            if ((lane & 31) == 0 && !ready && !dry) {
-                tk = atomicAdd(head, 1u);
-                if (tk < total) { const size_t at = (size_t)sub * q_cap + tk; pc = q_pc[at]; irg = q_rng[at]; L = (u32)irg; R = (u32)(irg >> 32); ready = true; }
-                else dry = true;
-                tk = NO_TICKET;
-            }
-#endif
             if (have_item && !ready) { pc = ipc; L = (u32)irg; R = (u32)(irg >> 32); ready = true; have_item = false; }
             if (tk != NO_TICKET && !have_item) {
                 if (tk < total) { const size_t at = (size_t)sub * q_cap + tk; ipc = q_pc[at]; irg = q_rng[at]; have_item = true; }
@@ -1182,16 +1029,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
             if ((lane & 31) == 0 && !ready && !have_item && tk == NO_TICKET && !dry) tk = atomicAdd(head, 1u);
             const u64 rm = __ballot(ready);
             if (!rm) { if (__ballot(tk != NO_TICKET || have_item)) continue; break; }
-#if HPX_LOOKAHEAD == 1
-            ext_pass_la(ready, pc, L, R, cw, ah, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE] EXT_TRACE_PASS);
-#elif HPX_LOOKAHEAD == 2
-            // the bulk of the launch is bound by instruction issue (four waves per SIMD, all running rounds): the plain pass.  Once the sub-queue is dry what is
-            // left is the climb from the last items to the root — lone waves whose siblings finished long ago: the look-ahead pass
-            if (__ballot(dry)) ext_pass_la(ready, pc, L, R, cw, ah, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE] EXT_TRACE_PASS);
-            else ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], prof EXT_TRACE_PASS);
-#else
             ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], prof EXT_TRACE_PASS);
-#endif
         }
         return;
     }
@@ -1202,12 +1040,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         u32 pc = 0, L = 0, R = 0;
         if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
         ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
-#if HPX_LOOKAHEAD == 1
-        ExtAhead ah; ah.q = INV; ah.q_known = false; ah.sib_have = false; ah.sid = INV; ah.srep = INV; ah.sb = box_empty();
-        while (__ballot(ready)) ext_pass_la(ready, pc, L, R, cw, ah, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE] EXT_TRACE_PASS);
-#else
         while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], prof EXT_TRACE_PASS);
-#endif
     }
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where k_hploc_ext spends its time (measurement build: tools/build_variant.sh ext_t "-DABL_EXT_TIMING -DHPX_LOOKAHEAD=0").
+"""Where k_hploc_ext spends its time (measurement build: tools/build_variant.sh ext_t "-DABL_EXT_TIMING").
 Usage (GPU box):  BVH_MI355X_LIB=build/variants/libbvh_ext_t.so python tools/ext_timing.py [N=10000000]"""
 import ctypes as C, os, sys
 import numpy as np, torch

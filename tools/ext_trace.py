@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the large tasks (> n / 4096 leaves) of k_hploc_ext (measurement build: tools/build_variant.sh tr0 "-DABL_EXT_TRACE -DHPX_LOOKAHEAD=0").
+"""Timeline of the large tasks (> n / 4096 leaves) of k_hploc_ext (measurement build: tools/build_variant.sh tr0 "-DABL_EXT_TRACE").
 Usage (GPU box):  BVH_MI355X_LIB=build/variants/libbvh_tr0.so python tools/ext_trace.py [N=10000000]"""
 import ctypes as C, os, sys
 import numpy as np, torch
