@@ -598,6 +598,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
                          //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
 #endif
+#ifndef HPB_PREPROBE
+#define HPB_PREPROBE 1   // 1: two probes at p - 8 / p + 9 decide most gaps before the binary searches for a node's range (the searches run compacted, one gap per thread)
+#endif
 #ifndef HPB_LEAN
 #define HPB_LEAN 0       // 1: 20.3 KB of LDS instead of 22.9 (eight workgroups per CU): the key window shares its storage with the rounds' key words and is
 #endif                   //    re-read for the hand-over; level counters sized for the key type
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
     __shared__ u32 s_cnt[NLV], s_off[NLV];
-    __shared__ u32 s_npub, s_nready, s_qbase;
+    __shared__ u32 s_npub, s_nready, s_qbase, s_ncand;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
 #if !HPB_LEAN
     __shared__ u64 s_nnf[NT + 8];                    // per wave: 64 nearest-neighbour key words of the PLOC rounds (+ 8: nn_search_il's unmasked atomics of the last
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #endif
     for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
     if (tid < NLV) s_cnt[tid] = 0u;
-    if (tid == 0) { s_npub = 0u; s_nready = 0u; }
+    if (tid == 0) { s_npub = 0u; s_nready = 0u; s_ncand = 0u; }
     __syncthreads();
     if (dbg == 1) return;
 
@@ -673,13 +676,40 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     const int jmin = g0 ? (int)g0 - 1 : 0;
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
     auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + KM]; };
-    int my_lv[PER]; u32 my_pos[PER];
+    int my_lv[PER]; u32 my_pos[PER], my_gap[PER];
+#if HPB_PREPROBE
+    // Only ~9 % of the gaps are merge tasks, another few per cent are lopsided small nodes or sit near a rim of the tile, yet the two binary searches below cost
+    // ~160 VALU instructions per gap: two probes at p - 8 and p + 9 first — neither inside means the node spans at most [p - 7, p + 8], 16 leaves, inside the
+    // tile: no task, not external — and only the gaps that survive are compacted (s_task is free until the level sort) and searched, one per thread.
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const u32 k = (u32)tid + (u32)i * NT;
         const u32 pc = g0 + k;
-        my_lv[i] = -1; my_pos[i] = 0;
         if (k < nleaf && pc < ni) {
+            const int p = (int)pc;
+            const K kp = wkey(p);
+            const int c0 = plen(kp, (u32)p, wkey(p + 1), (u32)p + 1u);
+            const bool small = p - 8 >= jmin && p + 9 <= jmax && !shares_prefix(wkey(p - 8), (u32)(p - 8), kp, (u32)p, c0) && !shares_prefix(wkey(p + 9), (u32)(p + 9), kp, (u32)p, c0);
+            if (small) m_range[k] = 0u;
+            else s_task[atomicAdd(&s_ncand, 1u)] = (unsigned short)k;
+        }
+    }
+    __syncthreads();
+    const u32 ncand = s_ncand;
+#endif
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+#if HPB_PREPROBE
+        const u32 ci = (u32)tid + (u32)i * NT;
+        const bool on = ci < ncand;
+        const u32 k = on ? (u32)s_task[ci] : 0u;
+#else
+        const u32 k = (u32)tid + (u32)i * NT;
+        const bool on = k < nleaf && g0 + k < ni;
+#endif
+        const u32 pc = g0 + k;
+        my_lv[i] = -1; my_pos[i] = 0; my_gap[i] = k;
+        if (on) {
             const int p = (int)pc;
             const K kp = wkey(p);
             const int c0 = plen(kp, (u32)p, wkey(p + 1), (u32)p + 1u);
@@ -714,7 +744,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)((u32)tid + (u32)i * NT);
+    for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)my_gap[i];
     __syncthreads();
     if (dbg == 2) return;
 #ifdef BVH_ABLATION       // measurement build: merge tasks run by the tile kernel (word 2 of sub-queue 0's padded head; read through BVH_OPT_DEBUG_TASKS_LOCAL)
