@@ -113,6 +113,21 @@ __device__ __forceinline__ Box box_load(const bvh_aabb* p) {
     const float2 a = f[0], b = f[1], c = f[2];
     return { a.x, a.y, b.x, b.y, c.x, c.y };
 }
+// the gather form (one random 24-byte record per lane): a 16-byte + an 8-byte load instead of three 8-byte ones — the record is 8-byte aligned and a multi-dword
+// global load only needs dword alignment, so the texture-address unit sees two lane requests per box instead of three
+#ifndef BVH_GATHER_X4
+#define BVH_GATHER_X4 1
+#endif
+__device__ __forceinline__ Box box_gather(const bvh_aabb* p) {
+#if BVH_GATHER_X4
+    typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+    const f4a8 a = *reinterpret_cast<const f4a8*>(p);
+    const float2 c = reinterpret_cast<const float2*>(p)[2];
+    return { a.x, a.y, a.z, a.w, c.x, c.y };
+#else
+    return box_load(p);
+#endif
+}
 __device__ __forceinline__ Box box_load_u(const bvh_aabb* p) {
     const float* f = reinterpret_cast<const float*>(p);
     return { f[0], f[1], f[2], f[3], f[4], f[5] };

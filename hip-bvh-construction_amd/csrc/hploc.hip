@@ -99,7 +99,7 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
         rep = c_start + s; id = ni + rep;
         if (SETUP) {
             const u32 prim = svals[rep];
-            b = box_load(boxes + prim);
+            b = box_gather(boxes + prim);
             float* f = reinterpret_cast<float*>(leaves + rep);
             reinterpret_cast<u32*>(f)[0] = prim;
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         const u32 k = (u32)tid + (u32)i * NT;
         if (k < nleaf) {
             const u32 g = g0 + k, prim = svals[g];
-            const Box b = box_load(boxes + prim);
+            const Box b = box_gather(boxes + prim);
             float* f = reinterpret_cast<float*>(leaves + g);
             reinterpret_cast<u32*>(f)[0] = prim;
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;

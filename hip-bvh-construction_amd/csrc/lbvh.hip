@@ -76,7 +76,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __re
     if (g >= n) return;
     const u32 ni = n - 1;
     const u32 prim = svals[g];
-    Box box = box_load(boxes + prim);                       // = bounds of Triangle[prim] (:44), computed once in stage E
+    Box box = box_gather(boxes + prim);                       // = bounds of Triangle[prim] (:44), computed once in stage E
     node_store_agent(nodes + ni + g, prim, INV, box);       // leaf record {left = primIdx, right = INVALID} (:36-45)
     lbvh_climb<K, false>(LbvhWalker{ g, g + 1, ni + g, 0u, 0u, box, true }, skeys, nodes, slots, root_out, n);
 }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
     Box box = box_empty();
     if (g < n) {
         const u32 prim = svals[g];
-        box = box_load(boxes + prim);                                     // = bounds of Triangle[prim] (:44), computed once in stage E
+        box = box_gather(boxes + prim);                                     // = bounds of Triangle[prim] (:44), computed once in stage E
         node_store_plain(nodes + ni + g, prim, INV, box);                 // leaf record (:36-45); read again only by later launches
     }
     __syncthreads();
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
     const u32 ni = n - 1;
     {   // InitBvhNodesPrimRef (:164-194): leaf = {primRef.primIdx, INVALID, primRef.aabb}; PrimRef i = {i, bounds(tri i)}
         const u32 prim = svals[g];
-        node_store_plain(nodes + ni + g, prim, INV, box_load(boxes + prim));
+        node_store_plain(nodes + ni + g, prim, INV, box_gather(boxes + prim));
     }
     if (g >= ni) return;
     const u32 idx = g;

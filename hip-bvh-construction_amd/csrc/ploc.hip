@@ -159,7 +159,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
     auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
         if (FIRST) {
             const u32 prim = svals[g];
-            b = box_load(boxes + prim); id = (u32)g + ni;
+            b = box_gather(boxes + prim); id = (u32)g + ni;
             if (own) {
                 float* f = reinterpret_cast<float*>(leaves + g);
                 reinterpret_cast<u32*>(f)[0] = prim;
