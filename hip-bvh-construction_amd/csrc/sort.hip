@@ -79,6 +79,9 @@ constexpr int SORT_NARROW_NT = 1024, SORT_NARROW_IPT = SORT_TILE / 1024;
 static_assert(SORT_NARROW_NT * SORT_NARROW_IPT == SORT_TILE, "the status rows are sized for SORT_TILE-pair tiles");
 template <typename K> struct SortWide { static constexpr int NT = 512, IPT = 13; };
 template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };    // 5120-pair tiles, 68 KB: 8 passes at 10 M 0.656 (256 x 20) -> 0.610 ms; 512 x 8: 0.657, 512 x 12: 0.731
+#ifndef SORT_EARLY_PUBLISH
+#define SORT_EARLY_PUBLISH 0     // 1: the totals go out before the ranking (A/B switch; measured slower, see the comment at its use)
+#endif
 #ifndef SORT_EXCHANGE_FIRST
 #define SORT_EXCHANGE_FIRST 1
 #endif
@@ -98,6 +101,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     __shared__ u32 s_vals[TILE];
     __shared__ u64 s_wsum[NW];
     __shared__ u32 s_tile;
+#if SORT_EARLY_PUBLISH
+    __shared__ u32 s_cnt[SORT_RADIX];
+#endif
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
 #ifdef BVH_ABLATION
@@ -124,6 +130,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     if (dig) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
+#if SORT_EARLY_PUBLISH
+        s_cnt[tid] = 0;
+#endif
     }
     __syncthreads();
     const u32 tile = s_tile;
@@ -148,6 +157,19 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     if (dbg & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     SORT_STAMP();                                    // 1: ticket + loads landed
+#if SORT_EARLY_PUBLISH
+    // ---- A/B switch (off): the tile's digit totals go out BEFORE the ranking (a plain LDS-atomic count).  Measured on the MI355X, 10 M keys, round 3:
+    // empty polls per tile 7.3 -> 5.7 and the look-back 32 k -> 28 k of a tile's 68 k ticks, but four passes 0.244 -> 0.252 ms (2 M: 0.0949 -> 0.0956).  What a
+    // tile waits for is not its predecessors' ranking: with ticket order (BVH_SORT_DEBUG=64) the empty polls vanish (0.8 per tile) and a look-back is
+    // still 5.4 steps of ~1.6 us — the loaded latency of a coherent (sc1) status load — while the ticket itself costs more than it saves (0.265 ms).
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const u32 local = (u32)(wave * WAVE * IPT + i * WAVE + lane);
+        if (local < valid) atomicAdd(&s_cnt[(u32)(key[i] >> shift) & digit_mask], 1u);
+    }
+    __syncthreads();
+    if (dig) st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | s_cnt[tid]);
+#endif
     // ---- rank inside the wave: lanes holding the same digit form a group (8 ballots); every member reads the wave's LDS
     // counter for that digit, the group's lowest lane bumps it; rank = counter-before + index inside the group.  Program order
     // (item-major, then lane) is exactly memory order inside the wave's span => stable.
@@ -182,7 +204,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         for (int w = 0; w < NW; ++w) { const u32 c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
         total = run;
         if ((u32)tid == digit_mask) total -= (u32)TILE - valid;     // padding keys (all ones) carry the top digit; they are not data
+#if !SORT_EARLY_PUBLISH
         st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | total);
+#endif
     }
     // ---- exclusive scans over the 256 digits (wave scan + LDS hop), two in one: the tile's digit totals -> s_binoff, and the pass's
     // raw global digit counts -> gexcl (every tile redoes that 256-entry scan from L2: cheaper than a kernel launch per sort)
