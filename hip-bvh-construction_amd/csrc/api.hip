@@ -68,6 +68,7 @@ struct bvh_ctx {
     // (HIP error, early return) makes the next one re-initialise the words instead of silently producing wrong trees.
     bool scratch_dirty = false;
     hipEvent_t ev[8] = {};
+    u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
     int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
 };
@@ -179,7 +180,8 @@ struct Bind { int prev = -1; bool ok = true;
 // PLOC++ iteration driver: batches of device-side iterations, one small read-back per batch (src/PLOC++Bvh.cpp:132-152
 // reads back after EVERY iteration).
 int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const u32* d_svals, const PlocScratch& sc, uint32_t* iterations_out) {
-    u32 host_state[PLOC_STATE_WORDS];
+    u32* const host_state = c->h_pinned + 16;                // (pinned: the per-batch read-back does not go through a staging buffer)
+    constexpr size_t state_bytes = PLOC_STATE_WORDS * sizeof(u32);
     int first = 0, parity = 0;
     bool fresh = true;
     // iterations needed grow by ~3 per doubling of n (measured: 30 at 262 k, 45 at 10 M); the first batch aims slightly above
@@ -190,7 +192,7 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
     for (uint32_t guard = 0; guard < n / 16u + 4096u; ++guard) {
         if (first + batch > PLOC_MAX_ITERS) {
             // restart the per-iteration bookkeeping with the current count (pathologically slow convergence only)
-            HIP_TRY(hipMemcpyAsync(host_state, sc.state, sizeof host_state, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(host_state, sc.state, state_bytes, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             const u32 count = host_state[first];
             parity = (parity + first) & 1;
@@ -199,7 +201,7 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
         }
         ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh);
         fresh = false;
-        HIP_TRY(hipMemcpyAsync(host_state, sc.state, sizeof host_state, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(host_state, sc.state, state_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const u32 count = host_state[first + batch];
         if (count <= 1) { if (iterations_out) *iterations_out = host_state[2 * PLOC_MAX_ITERS + 1]; return 0; }
@@ -290,6 +292,7 @@ int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return -(int)e; } c->own_stream = true; }
     for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { delete c; return -(int)r; } }
+    { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocDefault); if (r != hipSuccess) { delete c; return -(int)r; } }
     *out = c;
     return 0;
 }
@@ -302,6 +305,7 @@ void bvh_ctx_destroy(bvh_ctx* c) {
     if (c->arena) hipFree(c->arena);
     if (c->tris) hipFree(c->tris);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -406,7 +410,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     r = begin_emit(c); if (r) return r;
     launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, false, (int)c->options[BVH_OPT_LBVH_SCHEDULER]);
     r = end_emit(c); if (r) return r;
-    if (root_out) { HIP_TRY(hipMemcpyAsync(root_out, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    if (root_out) { HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); *root_out = c->h_pinned[0]; }
     return 0;
 }
 
@@ -486,8 +490,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (install.on) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
-        HIP_TRY(hipMemcpyAsync(&out->root, c->small, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, s));      // (pinned: a copy into pageable memory goes through a staging buffer)
         HIP_TRY(hipStreamSynchronize(s));
+        out->root = c->h_pinned[0];
     }
     out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = c->scene;
     out->d_sorted_keys = c->skeys; out->d_sorted_vals = c->svals;
