@@ -68,6 +68,7 @@ struct bvh_ctx {
     // (HIP error, early return) makes the next one re-initialise the words instead of silently producing wrong trees.
     bool scratch_dirty = false;
     hipEvent_t ev[8] = {};
+    uint32_t ploc_last_n = 0, ploc_last_iters = 0;   // size and iteration count of the last PLOC++ build (run_ploc aims its first batch of launches at it)
     u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
     int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
@@ -187,6 +188,9 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
     // iterations needed grow by ~3 per doubling of n (measured: 30 at 262 k, 45 at 10 M); the first batch aims slightly above
     // (round 2: 30 at 262 k, 34 at 2 M, 40 at 10 M on uniform meshes — two more per doubling; a launch after the end still costs ~5 us)
     int batch = 32; for (uint32_t m = n; m > 262144u; m >>= 1) batch += 2; if (batch > 80) batch = 80;
+    // rebuilds of a scene of the same size (animation frames; the benchmark loop) need the same number of iterations give or take one: aim one above the
+    // previous build's count instead of two to four (an iteration launched after the end costs ~5 us; one short costs a read-back and a second batch)
+    if (c->ploc_last_n == n && c->ploc_last_iters > 0 && c->ploc_last_iters + 1 < PLOC_MAX_ITERS) batch = (int)c->ploc_last_iters + 1;
     // every iteration merges at least the globally closest pair, so n iterations always suffice (a collinear, zero-area scene needs
     // almost that many: every union has area 0 and only the lowest pair of a chunk is mutual); the reference loops the same way
     for (uint32_t guard = 0; guard < n / 16u + 4096u; ++guard) {
@@ -204,7 +208,11 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
         HIP_TRY(hipMemcpyAsync(host_state, sc.state, state_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const u32 count = host_state[first + batch];
-        if (count <= 1) { if (iterations_out) *iterations_out = host_state[2 * PLOC_MAX_ITERS + 1]; return 0; }
+        if (count <= 1) {
+            c->ploc_last_n = n; c->ploc_last_iters = host_state[2 * PLOC_MAX_ITERS + 1];
+            if (iterations_out) *iterations_out = host_state[2 * PLOC_MAX_ITERS + 1];
+            return 0;
+        }
         first += batch; batch = 16;
     }
     return BVH_E_INTERNAL;

@@ -355,14 +355,22 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
 #endif
 }
 
-__global__ void k_ploc_init(u32* state, u32 n) { if (threadIdx.x == 0) state[0] = n; }
+// one launch clears the per-iteration bookkeeping (two memsets + a one-thread kernel before: three launch boundaries of ~2 us in front of every build)
+__global__ __launch_bounds__(256) void k_ploc_init(u32* __restrict__ state, u32 count, uint4* __restrict__ status, u32 status_vecs, u64* __restrict__ status_tail, u32 tail_words) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (u32 i = t; i < status_vecs; i += stride) status[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < tail_words) status_tail[t] = 0ull;
+    if (t < (u32)PLOC_STATE_WORDS) state[t] = t == 0u ? count : 0u;
+}
 
 // state words: counts[0..MAX_ITERS] | tickets[0..MAX_ITERS) | iterations done
 void ploc_begin(hipStream_t s, const PlocScratch& sc, uint32_t n) { ploc_reset(s, sc, n, n); }
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count) {
-    hipMemsetAsync(sc.state, 0, PLOC_STATE_WORDS * sizeof(u32), s);
-    hipMemsetAsync(sc.status, 0, (size_t)PLOC_MAX_ITERS * ploc_chunks(n) * sizeof(u64), s);
-    hipLaunchKernelGGL(k_ploc_init, dim3(1), dim3(64), 0, s, sc.state, count);
+    static_assert(PLOC_STATE_WORDS <= 256, "k_ploc_init: the state words are written by the first workgroup");
+    const size_t words = (size_t)PLOC_MAX_ITERS * ploc_chunks(n);          // u64 status words (the array is 256-byte aligned: 16-byte stores)
+    const u32 vecs = (u32)(words / 2), tail = (u32)(words % 2);
+    u32 blocks = (vecs + 255u) / 256u; if (blocks < 1u) blocks = 1u; if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(256), 0, s, sc.state, count, reinterpret_cast<uint4*>(sc.status), vecs, sc.status + (size_t)vecs * 2, tail);
 }
 // enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads.  The host does not
 // know the cluster count of an iteration; it only shapes the launch from a guess (C shrinks by ~20 % per iteration): any grid
