@@ -601,6 +601,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #ifndef HPB_PREPROBE
 #define HPB_PREPROBE 1   // 1: two probes at p - 8 / p + 9 decide most gaps before the binary searches for a node's range (the searches run compacted, one gap per thread)
 #endif
+#ifndef HPB_PAIR_SORT
+#define HPB_PAIR_SORT 1  // 1: a level's tasks are ordered by size class before they are dealt to the waves' halves
+#endif
 #ifndef HPB_LEAN
 #define HPB_LEAN 0       // 1: 20.3 KB of LDS instead of 22.9 (eight workgroups per CU): the key window shares its storage with the rounds' key words and is
 #endif                   //    re-read for the hand-over; level counters sized for the key type
@@ -677,6 +680,12 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
     auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + KM]; };
     int my_lv[PER]; u32 my_pos[PER], my_gap[PER];
+#if HPB_PAIR_SORT
+    u32 my_cls[PER];
+    auto lv_total = [](u32 w) -> u32 { return (w & 63u) + ((w >> 6) & 63u) + ((w >> 12) & 63u) + ((w >> 18) & 63u) + ((w >> 24) & 63u); };
+#else
+    auto lv_total = [](u32 w) -> u32 { return w; };
+#endif
 #if HPB_PREPROBE
     // Only ~9 % of the gaps are merge tasks, another few per cent are lopsided small nodes or sit near a rim of the tile, yet the two binary searches below cost
     // ~160 VALU instructions per gap: two probes at p - 8 and p + 9 first — neither inside means the node spans at most [p - 7, p + 8], 16 leaves, inside the
@@ -731,21 +740,40 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 if ((u32)(hi - lo + 1) > (u32)ABL_SKIP_ABOVE) continue;
 #endif
                 my_lv[i] = NLEV - 1 - c0;
+#if HPB_PAIR_SORT
+                // the level's tasks are grouped by size class (6-bit counters packed in the level's word: at most T / 17 <= 60 disjoint tasks per level), so that
+                // the two tasks of a wave pass need about the same number of rounds (a pass lasts as long as the longer of its two tasks)
+                const u32 sz = (u32)(hi - lo + 1);
+                my_cls[i] = sz > 32u ? 4u : (sz - 17u) >> 2;
+                my_pos[i] = (atomicAdd(&s_cnt[my_lv[i]], 1u << (6u * my_cls[i])) >> (6u * my_cls[i])) & 63u;
+#else
                 my_pos[i] = atomicAdd(&s_cnt[my_lv[i]], 1u);
+#endif
             }
         }
     }
     __syncthreads();
     if (tid < 64) {                                  // exclusive scan of the (<= 128) level counts, two per lane
-        const u32 v0 = 2 * tid < NLV ? s_cnt[2 * tid] : 0u, v1 = 2 * tid + 1 < NLV ? s_cnt[2 * tid + 1] : 0u; u32 incl = v0 + v1;
+        const u32 v0 = 2 * tid < NLV ? lv_total(s_cnt[2 * tid]) : 0u, v1 = 2 * tid + 1 < NLV ? lv_total(s_cnt[2 * tid + 1]) : 0u; u32 incl = v0 + v1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
         if (2 * tid + 1 < NLV) { s_off[2 * tid] = incl - v0 - v1; s_off[2 * tid + 1] = incl - v1; }
     }
     __syncthreads();
 #pragma unroll
+#if HPB_PAIR_SORT
+    for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) {
+        const u32 w = s_cnt[my_lv[i]];
+        const u32 before = lv_total(w & ((1u << (6u * my_cls[i])) - 1u));            // tasks of the lower classes on this level
+        s_task[s_off[my_lv[i]] + before + my_pos[i]] = (unsigned short)my_gap[i];
+    }
+    __syncthreads();
+    if (tid < NLV) s_cnt[tid] = lv_total(s_cnt[tid]);                                 // the level loop reads plain counts
+    __syncthreads();
+#else
     for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)my_gap[i];
     __syncthreads();
+#endif
     if (dbg == 2) return;
 #ifdef BVH_ABLATION       // measurement build: merge tasks run by the tile kernel (word 2 of sub-queue 0's padded head; read through BVH_OPT_DEBUG_TASKS_LOCAL)
     if (tid == 0) { u32 t = 0; for (int lv = 0; lv < NLEV; ++lv) t += s_cnt[lv]; atomicAdd(q_count + 2, t); }
