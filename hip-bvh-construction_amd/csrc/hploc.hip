@@ -379,6 +379,30 @@ struct TileList {            // k_hploc_block: id / rep tile-relative in 16 bits
     __device__ __forceinline__ Tag tag_at(u32 pos) const { return ir[pos]; }
     __device__ __forceinline__ void invalidate(u32 pos) const { ir[pos] = 0xFFFFFFFFu; }
 };
+struct WaveList {            // k_hploc_ext: a wave's two 32-slot work lists with full 32-bit ids / reps (8-byte tag + three 8-byte box planes per position)
+    typedef u64 Tag;         // id | rep << 32
+    u64* ir; float2* b0; float2* b1; float2* b2;
+    static __device__ __forceinline__ Tag invalid_tag() { return ~0ull; }
+    static __device__ __forceinline__ Tag make(u32 id, u32 rep) { return (u64)id | ((u64)rep << 32); }
+    static __device__ __forceinline__ bool is_valid(Tag t) { return (u32)t != INV; }
+    __device__ __forceinline__ u32 id(Tag t) const { return (u32)t; }
+    __device__ __forceinline__ u32 rep(Tag t) const { return (u32)(t >> 32); }
+    __device__ __forceinline__ Tag with_node(Tag t, u32 node) const { return (t & 0xFFFFFFFF00000000ull) | (u64)node; }
+    __device__ __forceinline__ void load(u32 pos, Tag& t, Box& b) const {
+        t = ir[pos];
+        const float2 q0 = b0[pos], q1 = b1[pos], q2 = b2[pos];
+        b = { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
+    }
+    __device__ __forceinline__ void store(u32 pos, Tag t, const Box& b) const {
+        ir[pos] = t; b0[pos] = make_float2(b.lx, b.ly); b1[pos] = make_float2(b.lz, b.hx); b2[pos] = make_float2(b.hy, b.hz);
+    }
+    __device__ __forceinline__ Box load_box(u32 pos) const {
+        const float2 q0 = b0[pos], q1 = b1[pos], q2 = b2[pos];
+        return { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y };
+    }
+    __device__ __forceinline__ Tag tag_at(u32 pos) const { return ir[pos]; }
+    __device__ __forceinline__ void invalidate(u32 pos) const { ir[pos] = ~0ull; }
+};
 // One task per 32-lane half.  In: have / final_ (uniform per half), cnt, and the lane's cluster (tag, b; invalid beyond cnt) as loaded from the list.
 // Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
 // IL: interleaved lane layout (nn_search_il): slot is NOT lane & 31; below = the half's lanes that hold lower slots; o_in = box of slot + 1.
@@ -922,11 +946,16 @@ __device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap,
 #define EXT_TRACE_ARGS
 #define EXT_TRACE_PASS
 #endif
+#ifndef HPX_LDS_LIST
+#define HPX_LDS_LIST 0   // 1: k_hploc_ext's rounds run on a per-wave work list in LDS (ploc_rounds_lds, as in the tile kernel); 0 (default): register lists + crossbar
+                         //    (ploc_rounds).  Measured (round 3, trees equal): 10 M 0.229 vs 0.213 ms, 2 M 0.097 vs 0.0945 — here the list has to be written and read back around
+                         //    every task (in the tile kernel it lives in LDS anyway), and the kernel needs 100 instead of 90 VGPRs
+#endif
 struct ExtCarry { u32 id, rep; Box b; int side; };    // a half's survivors after a task (slot = lane & 31 < 16); side (owner lane): 0 none, 1 = they are
                                                       // the LEFT child of the half's next task, 2 = the RIGHT child
 template <typename K>
 __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, ExtCarry& cw, const K* __restrict__ skeys,
-                                         const bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn, u32* prof = nullptr EXT_TRACE_ARGS) {
+                                         const bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn, const WaveList& wl, u32* prof = nullptr EXT_TRACE_ARGS) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
 #ifdef ABL_EXT_TRACE
     const u64 tr0 = __builtin_amdgcn_s_memrealtime(); const u32 trL = L, trR = R; u32 tr_rounds = 0;
@@ -975,6 +1004,15 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     const u64 t2 = __builtin_amdgcn_s_memtime();
 #elif defined(ABL_EXT_TRACE) && !defined(EXT_TRACE_NOHOOK)
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, [&]() { ++tr_rounds; });
+#elif HPX_LDS_LIST
+    {   // the rounds run on the half's list in LDS (ploc_rounds_lds: the partner is read, survivors are written to their rank — no crossbar operations,
+        // ~50 fewer VALU instructions per round); the list is filled from the left-packed registers and the survivors are read back into them
+        WaveList::Tag tag = WaveList::make(w.id, w.rep);
+        wl.store((u32)lane, tag, w.b);
+        u32 cnt = w.cnt;
+        ploc_rounds_lds<true, false>(have, w.final_, cnt, tag, w.b, (u32)hbase, 32u, (u32)hbase, (u32)hbase + 31u, wl, nodes, zero_parent, lane, slot, hbase, nn);
+        w.cnt = cnt; w.id = wl.id(tag); w.rep = wl.rep(tag);
+    }
 #else
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn);
 #endif
@@ -1045,7 +1083,11 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, u32* q_count, u32 q_cap, u32 n) {
     __shared__ u64 s_nn[256 / WAVE][WAVE];
+    __shared__ u64 s_lir[256 / WAVE][WAVE];
+    __shared__ float2 s_lb[3][256 / WAVE][WAVE + 1];
     const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    const WaveList wl{ s_lir[wv], s_lb[0][wv], s_lb[1][wv], s_lb[2][wv] };
     const u32 nwaves = gridDim.x * (256 / WAVE);
     const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
     const u32 sub = wid % HPQ_SUB;                                       // (nwaves is a multiple of HPQ_SUB)
@@ -1087,7 +1129,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
             if ((lane & 31) == 0 && !ready && !have_item && tk == NO_TICKET && !dry) tk = atomicAdd(head, 1u);
             const u64 rm = __ballot(ready);
             if (!rm) { if (__ballot(tk != NO_TICKET || have_item)) continue; break; }
-            ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], prof EXT_TRACE_PASS);
+            ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], wl, prof EXT_TRACE_PASS);
         }
         return;
     }
@@ -1098,7 +1140,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         u32 pc = 0, L = 0, R = 0;
         if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
         ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
-        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], prof EXT_TRACE_PASS);
+        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], wl, prof EXT_TRACE_PASS);
     }
 }
 

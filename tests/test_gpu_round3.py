@@ -108,3 +108,22 @@ def test_batch_allgather_is_timed_outside_the_group(pkg):
         assert rep.allgather_us > 0.5, rep.allgather_us            # a collective (or its one-rank copy) takes microseconds, not an empty interval
     finally:
         L.bvh_batch_destroy(h)
+
+
+def test_ploc_first_batch_follows_the_previous_build(pkg, orc, ctx):
+    """run_ploc aims its first batch of launches one above the previous same-size build's iteration count (csrc/api.hip; the reference reads back after
+    every iteration, src/PLOC++Bvh.cpp:132-152).  Same n, different meshes: a scene that needs MORE iterations than its predecessor (second batch), fewer,
+    and the same again — node arrays byte-identical to the oracle's and the iteration counts the oracle's every time."""
+    n = 40_000
+    meshes = [pkg.meshgen.uniform(n, 3), pkg.meshgen.sponza_like(n, 5)[:n], pkg.meshgen.bunny_like(n, 7)[:n], pkg.meshgen.uniform(n, 3)]
+    flat = pkg.meshgen.uniform(n, 9).copy(); flat.view(np.float32).reshape(n, -1)[:, [2, 5, 8]] *= 1e-4          # a nearly flat scene: many more iterations
+    meshes.insert(2, flat)
+    iters = []
+    for tris in meshes:
+        assert len(tris) == n
+        b = pkg.PLOCNew().build(ctx, tris)
+        got = b.download(); ref = orc.build_tree(2, tris)
+        assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["leaves"].tobytes() == ref["leaves"].tobytes()
+        assert b.timings.ploc_iterations == ref["stats"]["iterations"]
+        iters.append(b.timings.ploc_iterations)
+    assert iters[0] == iters[-1] and len(set(iters)) > 1, iters      # (the sequence really exercised a change of the count)
