@@ -68,6 +68,8 @@ struct bvh_ctx {
     // (HIP error, early return) makes the next one re-initialise the words instead of silently producing wrong trees.
     bool scratch_dirty = false;
     hipEvent_t ev[8] = {};
+    int scene_slot = 0;               // which of the two scene extents the next build uses
+    bool scene_ready = false;         // that extent holds Aabb::reset values (written by the previous build's Morton kernel); false: reset it explicitly
     uint32_t ploc_last_n = 0, ploc_last_iters = 0;   // size and iteration count of the last PLOC++ build (run_ploc aims its first batch of launches at it)
     u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
@@ -107,7 +109,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     Carver k{base};
     const size_t n = cap;
     c->boxes = k.take<bvh_aabb>(n);
-    c->scene = k.take<float>(8);
+    c->scene = k.take<float>(16);          // two extents of 8 floats: builds alternate, the Morton kernel of one build resets the other for the next
     c->keys = reinterpret_cast<u32*>(k.take<u64>(n)); c->skeys = reinterpret_cast<u32*>(k.take<u64>(n)); c->svals = k.take<u32>(n);
     c->sort.pairs0 = k.take<uint4>(n); c->sort.pairs1 = k.take<uint4>(n);
     c->sort.hist = k.take<u32>(SORT_HIST_COPIES * SORT_HIST_STRIDE);
@@ -144,6 +146,7 @@ int ensure_capacity(bvh_ctx* c, uint32_t n) {
     char* p = nullptr;
     HIP_TRY(hipMalloc(&p, total));
     c->arena = p; c->arena_bytes = total; c->cap = n;
+    c->scene_ready = false; c->scene_slot = 0;
     carve(c, p, n, &total);
     HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)n * sizeof(u64), c->stream));   // HPLOC dependency words: clean once, builds keep them clean
     HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)n * sizeof(u32), c->stream));    // two-pass LBVH exchange words: likewise
@@ -227,12 +230,12 @@ int stage_extents_valid(const bvh_build_input* in) {
         default: return BVH_E_INVALID_ARG;
     }
 }
-int stage_extents_fmt(hipStream_t s, const bvh_build_input* in, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true) {
+int stage_extents_fmt(hipStream_t s, const bvh_build_input* in, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr) {
     const int v = stage_extents_valid(in); if (v) return v;
     switch (in->tri_format) {
-        case BVH_TRI_PADDED64: launch_extents(s, in->d_tris, n, d_boxes, d_scene, reset_scene); return 0;
-        case BVH_TRI_PACKED36: launch_extents_packed(s, in->d_tris, n, d_boxes, d_scene, reset_scene); return 0;
-        case BVH_TRI_INDEXED:  launch_extents_indexed(s, in->d_vertices, in->d_indices, in->n_vertices, n, d_boxes, d_scene, reset_scene); return 0;
+        case BVH_TRI_PADDED64: launch_extents(s, in->d_tris, n, d_boxes, d_scene, reset_scene, prep); return 0;
+        case BVH_TRI_PACKED36: launch_extents_packed(s, in->d_tris, n, d_boxes, d_scene, reset_scene, prep); return 0;
+        case BVH_TRI_INDEXED:  launch_extents_indexed(s, in->d_vertices, in->d_indices, in->n_vertices, n, d_boxes, d_scene, reset_scene, prep); return 0;
         default: return BVH_E_INVALID_ARG;
     }
 }
@@ -470,12 +473,22 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     const int end_bit = key_bits == 64 ? 64 : 32;
     const int passes = sort_passes(0, end_bit);
     r = stage_extents_valid(in); if (r) return r;
-    sort_prepare(s, c->sort, n, passes, c->scene, c->hploc.queue_count, 64 * 32);    // + Aabb::reset of the scene extent + the emitters' queue heads
-    r = stage_extents_fmt(s, in, n, c->boxes, c->scene, false); if (r) return r;
+    // what a build needs cleared (digit histograms, look-back status rows and tile tickets of `passes` sort passes, the emitters' queue heads) is cleared by
+    // stage E's kernel itself; the scene extent of THIS build was reset by the previous build's Morton kernel (two extents, used alternately) — explicitly
+    // only for a context's first build, after a re-allocation or after a build that failed half-way
+    float* const scene = c->scene + 8 * c->scene_slot;
+    float* const scene_next = c->scene + 8 * (c->scene_slot ^ 1);
+    PrepArgs prep;
+    prep.hist = c->sort.hist; prep.hist_words = (u32)SORT_HIST_COPIES * SORT_HIST_STRIDE;
+    prep.status = reinterpret_cast<uint4*>(c->sort.status); prep.status_vecs = (u32)(((size_t)passes * sort_tiles(n) * SORT_RADIX) / 4);
+    prep.counters = c->sort.counters; prep.extra = c->hploc.queue_count; prep.extra_words = 64 * 32;
+    const bool explicit_reset = !c->scene_ready;
+    c->scene_ready = false;
+    r = stage_extents_fmt(s, in, n, c->boxes, scene, explicit_reset, &prep); if (r) return r;
     if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
     // M: CalculateMortonCodes (token CalculateMortonCodesTime); values are implicit (value i = i), produced by sort pass 0
-    if (key_bits == 64) launch_morton64(s, c->boxes, n, c->scene, reinterpret_cast<u64*>(c->keys), 60, c->sort.hist, passes);
-    else launch_morton(s, c->boxes, n, c->scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes);
+    if (key_bits == 64) launch_morton64(s, c->boxes, n, scene, reinterpret_cast<u64*>(c->keys), 60, c->sort.hist, passes, scene_next);
+    else launch_morton(s, c->boxes, n, scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes, scene_next);
     if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
     // S: radix sort (token SortingTime)
     if (key_bits == 64) sort_pairs64(s, c->sort, reinterpret_cast<const u64*>(c->keys), nullptr, n, reinterpret_cast<u64*>(c->skeys), c->svals, 0, end_bit, true);
@@ -495,6 +508,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
                                   out->d_leaves = c->leaves; out->layout = 1; break;
     }
     r = end_emit(c); if (r) return r;
+    c->scene_ready = true; c->scene_slot ^= 1;             // every launch was accepted: the Morton kernel has reset the other extent for the next build
     if (install.on) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
@@ -502,7 +516,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
         HIP_TRY(hipStreamSynchronize(s));
         out->root = c->h_pinned[0];
     }
-    out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = c->scene;
+    out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = scene;
     out->d_sorted_keys = c->skeys; out->d_sorted_vals = c->svals;
     out->n_internal = n - 1; out->n_leaves = n; out->key_bits = (uint32_t)key_bits; out->reserved = 0;
     out->d_tris = in->tri_format == BVH_TRI_INDEXED ? in->d_vertices : in->d_tris; out->d_morton_keys = c->keys;

@@ -19,17 +19,25 @@ struct KernelScope {
 };
 
 constexpr int EM_BLOCK = 256;
+// what the build path's first kernel clears before it starts (the stand-alone sort entry point clears the same through sort_prepare / k_prepare)
+struct PrepArgs { uint32_t* hist = nullptr; uint32_t hist_words = 0; uint4* status = nullptr; uint32_t status_vecs = 0; uint32_t* counters = nullptr;
+                  uint32_t* extra = nullptr; uint32_t extra_words = 0; };
+#ifdef BVH_ABLATION
+constexpr int SORT_COUNTER_CLEAR = 64;      // (+ the look-back statistics of the measurement build)
+#else
+constexpr int SORT_COUNTER_CLEAR = 8;       // = SORT_MAX_PASSES tile tickets
+#endif
 
 // ---- stage E / M (stage_em.hip)
 // reset_scene: launch the Aabb::reset of d_scene first (false when sort_prepare already did it)
-void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true);
-void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true);
-void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true);
+void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
+void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
+void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
 void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint32_t* d_keys, uint32_t* d_vals,
-                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes);
+                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes, float* d_reset_next = nullptr /* Aabb::reset of another extent (the next build's) */);
 // extended Morton code with a 60-bit budget in u64 keys (total_bits = 30 reproduces launch_morton's codes: the parity pin)
 void launch_morton64(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint64_t* d_keys, int total_bits,
-                     uint32_t* d_hist /*may be null*/, int passes);
+                     uint32_t* d_hist /*may be null*/, int passes, float* d_reset_next = nullptr);
 
 // ---- stage S (sort.hip): one-sweep LSD radix sort, SORT_BITS-bit digits
 constexpr int SORT_BITS = 8;
@@ -43,6 +51,7 @@ constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgr
 constexpr int SORT_IPT_WIDE = 20;                            // keys per thread for large inputs
 constexpr uint32_t SORT_WIDE_MIN_N = 1000000;
 constexpr int SORT_MAX_PASSES = 8;                          // 8 digits: 64-bit keys
+static_assert(SORT_COUNTER_CLEAR >= SORT_MAX_PASSES, "the build path's first kernel clears the tile tickets of every pass");
 // The digit histograms exist in SORT_HIST_COPIES copies (copy c at hist + c * SORT_HIST_STRIDE): a producer workgroup flushes its counts
 // into copy blockIdx % copies, a sort tile adds the copies up.  One address takes ~90 atomics/us on this chip: 2048 workgroups flushing
 // into ONE copy spent 23 us queueing on every bin (k_morton 88 us at 10 M, of which the stream is 45); with 16 copies it is 1.5 us.

@@ -50,8 +50,21 @@ __device__ __forceinline__ void block_reduce_scene(Box acc, float* __restrict__ 
     }
 }
 
+// The build path folds the per-build clearing (sort.hip k_prepare: digit histograms, look-back status rows, tile tickets / gate word, the emitters' queue
+// heads) into its first kernel: every workgroup clears a slice before it touches a triangle — one launch (and its ~2 us boundary) less per build.  The
+// scene extent cannot be reset here (this kernel's own atomics need it clean): the build path alternates between two extents and the Morton kernel of
+// one build resets the extent of the next (api.hip build_impl).
+__device__ __forceinline__ void prep_slice(const PrepArgs& p) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (u32 i = t; i < p.status_vecs; i += stride) p.status[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (u32 i = t; i < p.hist_words; i += stride) p.hist[i] = 0u;
+    for (u32 i = t; i < p.extra_words; i += stride) p.extra[i] = 0u;
+    if (p.counters && t < (u32)SORT_COUNTER_CLEAR) p.counters[t] = 0u;
+}
+
 __global__ __launch_bounds__(EX_BLOCK) void k_extents(const float4* __restrict__ tris, bvh_aabb* __restrict__ boxes,
-                                                      float* __restrict__ scene, u32 n) {
+                                                      float* __restrict__ scene, u32 n, PrepArgs prep) {
+    prep_slice(prep);
     Box acc = box_empty();
     const u32 stride = gridDim.x * EX_BLOCK;
     for (u32 i = blockIdx.x * EX_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -72,7 +85,8 @@ __global__ __launch_bounds__(EX_BLOCK) void k_extents(const float4* __restrict__
 // Packed: 9 floats per triangle (36-byte stride).  A block stages 256 triangles (9216 contiguous bytes) through LDS with
 // 16-byte loads; each thread then reads its 9 floats at a stride of 9 words (odd: conflict-free).  R 36 + W 24 B / prim.
 __global__ __launch_bounds__(EM_BLOCK) void k_extents_packed(const float* __restrict__ tris, bvh_aabb* __restrict__ boxes,
-                                                             float* __restrict__ scene, u32 n) {
+                                                             float* __restrict__ scene, u32 n, PrepArgs prep) {
+    prep_slice(prep);
     __shared__ float s_t[EM_BLOCK * 9];
     Box acc = box_empty();
     const u32 tiles = (n + EM_BLOCK - 1) / EM_BLOCK;
@@ -99,7 +113,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_extents_packed(const float* __rest
 
 // Indexed: float3 vertices + uint3 indices.  R 12 (indices) + 3 vertex gathers (12 B each, shared vertices hit in L2) + W 24 B / prim.
 __global__ __launch_bounds__(EX_BLOCK) void k_extents_indexed(const float* __restrict__ verts, const u32* __restrict__ idx, u32 n_verts,
-                                                              bvh_aabb* __restrict__ boxes, float* __restrict__ scene, u32 n) {
+                                                              bvh_aabb* __restrict__ boxes, float* __restrict__ scene, u32 n, PrepArgs prep) {
+    prep_slice(prep);
     Box acc = box_empty();
     const u32 stride = gridDim.x * EX_BLOCK;
     for (u32 i = blockIdx.x * EX_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -265,7 +280,8 @@ __device__ __forceinline__ u64 encode64(const MortonPlan& m, float p0, float p1,
 
 // u64 keys with a `total_bits` budget; the 8-bit digit histograms of the `passes` sort passes that follow are fused in as in k_morton
 __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
-                                                       u64* __restrict__ keys, u32 n, u32 total_bits, u32* __restrict__ hist, int passes) {
+                                                       u64* __restrict__ keys, u32 n, u32 total_bits, u32* __restrict__ hist, int passes, float* reset_next) {
+    if (reset_next && blockIdx.x == 0 && threadIdx.x < 6) reset_next[threadIdx.x] = threadIdx.x < 3 ? FMAX : -FMAX;     // Aabb::reset of the NEXT build's extent
     __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
     __shared__ u32 s_hist[8 * 256];
     if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext, total_bits);
@@ -296,7 +312,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
 template <int HIST_BITS>
 __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
                                                      u32* __restrict__ keys, u32* __restrict__ vals, u32 n,
-                                                     u32* __restrict__ hist, int passes) {
+                                                     u32* __restrict__ hist, int passes, float* reset_next) {
+    if (reset_next && blockIdx.x == 0 && threadIdx.x < 6) reset_next[threadIdx.x] = threadIdx.x < 3 ? FMAX : -FMAX;     // Aabb::reset of the NEXT build's extent
     __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
     constexpr int RADIX = HIST_BITS > 0 ? (1 << HIST_BITS) : 1;
     __shared__ u32 s_hist[HIST_BITS > 0 ? 4 * RADIX : 1];
@@ -345,37 +362,40 @@ static inline int ex_grid(u32 n) {            // ~4 primitives per thread, at mo
     return (int)(blocks < 512u ? (blocks ? blocks : 1u) : 512u);
 }
 
-void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene, bool reset_scene) {
+void launch_extents(hipStream_t s, const void* d_tris, u32 n, void* d_boxes, void* d_scene, bool reset_scene, const PrepArgs* prep) {
+    const PrepArgs pa = prep ? *prep : PrepArgs{};
     if (reset_scene) hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
     // (a variant in which four lanes read one 64-byte record with 16-byte loads and three of them store the box — every access fully
     // coalesced — runs in the same time: 0.180 vs 0.179 ms at 10 M, the kernel moves 880 MB at 4.9 TB/s either way)
     KernelScope ks(s, "k_extents");
-    hipLaunchKernelGGL(k_extents, dim3(ex_grid(n)), dim3(EX_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+    hipLaunchKernelGGL(k_extents, dim3(ex_grid(n)), dim3(EX_BLOCK), 0, s, (const float4*)d_tris, (bvh_aabb*)d_boxes, (float*)d_scene, n, pa);
 }
 
-void launch_extents_packed(hipStream_t s, const void* d_tris36, u32 n, void* d_boxes, void* d_scene, bool reset_scene) {
+void launch_extents_packed(hipStream_t s, const void* d_tris36, u32 n, void* d_boxes, void* d_scene, bool reset_scene, const PrepArgs* prep) {
+    const PrepArgs pa = prep ? *prep : PrepArgs{};
     if (reset_scene) hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
     KernelScope ks(s, "k_extents_packed");
-    hipLaunchKernelGGL(k_extents_packed, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float*)d_tris36, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+    hipLaunchKernelGGL(k_extents_packed, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const float*)d_tris36, (bvh_aabb*)d_boxes, (float*)d_scene, n, pa);
 }
-void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, u32 n_vertices, u32 n, void* d_boxes, void* d_scene, bool reset_scene) {
+void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, u32 n_vertices, u32 n, void* d_boxes, void* d_scene, bool reset_scene, const PrepArgs* prep) {
+    const PrepArgs pa = prep ? *prep : PrepArgs{};
     if (reset_scene) hipLaunchKernelGGL(k_reset_scene, dim3(1), dim3(64), 0, s, (float*)d_scene);
     KernelScope ks(s, "k_extents_indexed");
-    hipLaunchKernelGGL(k_extents_indexed, dim3(ex_grid(n)), dim3(EX_BLOCK), 0, s, (const float*)d_vertices, (const u32*)d_indices, n_vertices, (bvh_aabb*)d_boxes, (float*)d_scene, n);
+    hipLaunchKernelGGL(k_extents_indexed, dim3(ex_grid(n)), dim3(EX_BLOCK), 0, s, (const float*)d_vertices, (const u32*)d_indices, n_vertices, (bvh_aabb*)d_boxes, (float*)d_scene, n, pa);
 }
 
 void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
-                   u32* d_hist, int hist_bits, int passes) {
+                   u32* d_hist, int hist_bits, int passes, float* d_reset_next) {
     const dim3 g(em_grid(n)), b(EM_BLOCK);
     KernelScope ks(s, "k_morton");
-    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes);
-    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0);
+    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes, d_reset_next);
+    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0, d_reset_next);
 }
 
-void launch_morton64(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, uint64_t* d_keys, int total_bits, u32* d_hist, int passes) {
+void launch_morton64(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, uint64_t* d_keys, int total_bits, u32* d_hist, int passes, float* d_reset_next) {
     KernelScope ks(s, "k_morton64");
     hipLaunchKernelGGL(k_morton64, dim3(em_grid(n)), dim3(EM_BLOCK), 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, n, (u32)total_bits,
-                       d_hist, d_hist ? passes : 0);
+                       d_hist, d_hist ? passes : 0, d_reset_next);
 }
 
 } // namespace bvh
