@@ -127,3 +127,28 @@ def test_ploc_first_batch_follows_the_previous_build(pkg, orc, ctx):
         assert b.timings.ploc_iterations == ref["stats"]["iterations"]
         iters.append(b.timings.ploc_iterations)
     assert iters[0] == iters[-1] and len(set(iters)) > 1, iters      # (the sequence really exercised a change of the count)
+
+
+def test_scene_extent_is_fresh_for_every_build(pkg, orc):
+    """The build path double-buffers the scene extent (the Morton kernel of one build resets the extent the NEXT build reduces into, csrc/api.hip) and clears
+    its bookkeeping inside stage E's kernel.  A scene nested inside the previous one, a different builder, a failed build in between and a re-allocation
+    must all see a clean extent: scene box and sorted keys equal to the oracle's (CalculateSceneExtents / CalculateMortonCodes, src/CommonBlocksKernel.h:92-114,374-385)."""
+    ctx = pkg.Context(0)
+    try:
+        big = pkg.meshgen.uniform(30_000, 5)
+        small = pkg.meshgen.uniform(20_000, 6).copy()
+        v = small.view(np.float32).reshape(len(small), -1)
+        v[:, :9] = v[:, :9] * 0.01 + 0.4                                  # a scene well inside the first one's extent
+        seq = [(big, 3), (small, 3), (small, 1), (big, 2), (small, 0), (big, 3)]
+        for k, (tris, algo) in enumerate(seq):
+            if k == 3:                                                      # a build that fails before anything is enqueued ...
+                with pytest.raises(pkg.BvhError):
+                    pkg.BUILDERS[algo]().build_ex(ctx, 10, tris=None)
+            if k == 4:                                                      # ... and a re-allocation of the arena
+                ctx.reserve(200_000)
+            got = pkg.BUILDERS[algo]().build(ctx, tris).download()
+            ref = orc.build_tree(algo, tris)
+            assert got["scene"].tobytes() == ref["scene"].tobytes(), f"step {k}"
+            assert np.array_equal(got["sorted_keys"], ref["skeys"]) and np.array_equal(got["sorted_vals"], ref["svals"]), f"step {k}"
+    finally:
+        ctx.close()
