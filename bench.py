@@ -242,7 +242,7 @@ def main() -> None:
             roof["own_bytes_per_launch"] = own; roof["own_frac"] = round(own / (per_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     # ---- CPU baseline: reference's binned-SAH builder (oracle port), single thread, bounded sample of the same mesh
     cpu = None
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:                 # (rank 0 at N = 1 only: an N-GPU run does not hold its ranks for 23 s of CPU work)
         import oracle as orc
         m = min(args.cpu_sample, n)
         sample = np.ascontiguousarray(tris[:m])
