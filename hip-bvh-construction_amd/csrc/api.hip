@@ -456,6 +456,9 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
     return end_emit(c);
 }
 
+#ifndef LEAF_FROM_TRIS
+#define LEAF_FROM_TRIS 0
+#endif
 static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* tm) {
     const int key_bits = in->morton_bits == 60 ? 64 : 32;
     hipStream_t s = c->stream;
@@ -501,7 +504,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
         case BVH_LBVH_SINGLEPASS: launch_lbvh_single(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true, (int)c->options[BVH_OPT_LBVH_SCHEDULER]); break;
         case BVH_LBVH_TWOPASS:    launch_lbvh_two(s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->parent, c->flags, c->hploc.dep, c->small,
                                                   c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, true, (int)c->options[BVH_OPT_LBVH_SCHEDULER]); break;
-        case BVH_HPLOC:           emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
+        case BVH_HPLOC:           c->hploc.leaf_tris = (LEAF_FROM_TRIS && in->tri_format == BVH_TRI_PADDED64) ? in->d_tris : nullptr;
+                                  emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
+                                  c->hploc.leaf_tris = nullptr;
                                   out->d_leaves = c->leaves; out->layout = 1; break;
         case BVH_PLOCPP:          ploc_begin(s, c->ploc, n);
                                   r = run_ploc(c, n, c->nodes, c->leaves, c->boxes, c->svals, c->ploc, &ploc_iters); if (r) return r;

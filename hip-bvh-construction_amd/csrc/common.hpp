@@ -128,6 +128,13 @@ __device__ __forceinline__ Box box_gather(const bvh_aabb* p) {
     return box_load(p);
 #endif
 }
+// the bounds of a 64-byte Triangle record, with stage E's operations in stage E's order (stage_em.hip k_extents): the same bits as the box array holds
+__device__ __forceinline__ Box tri_box_gather(const float4* t) {
+    const float4 a = t[0], b = t[1];
+    const float c = reinterpret_cast<const float*>(t + 2)[0];
+    return { fminf(fminf(a.x, a.w), b.z), fminf(fminf(a.y, b.x), b.w), fminf(fminf(a.z, b.y), c),
+             fmaxf(fmaxf(a.x, a.w), b.z), fmaxf(fmaxf(a.y, b.x), b.w), fmaxf(fmaxf(a.z, b.y), c) };
+}
 __device__ __forceinline__ Box box_load_u(const bvh_aabb* p) {
     const float* f = reinterpret_cast<const float*>(p);
     return { f[0], f[1], f[2], f[3], f[4], f[5] };

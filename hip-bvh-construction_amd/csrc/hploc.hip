@@ -611,7 +611,7 @@ template <typename K, int T, int NT, int OCC>
 __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
                                                     bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent,
-                                                    u32* q_pc, u64* q_rng, u32* q_count, u32 q_cap, u32 n, int dbg) {
+                                                    u32* q_pc, u64* q_rng, u32* q_count, u32 q_cap, u32 n, int dbg, const float4* __restrict__ tris) {
     constexpr int PER = T / NT;                      // leaf positions (and gaps) per thread
     constexpr int NW = NT / WAVE;
     static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
@@ -628,6 +628,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #ifndef HPB_PAIR_SORT
 #define HPB_PAIR_SORT 1  // 1: a level's tasks are ordered by size class before they are dealt to the waves' halves
 #endif
+#ifndef HPB_PRIO
+#define HPB_PRIO 0       // A/B switch (off): s_setprio in the tile kernel — 1: a level's waves run at a priority that grows as the level thins out (<= 2 tasks: 3, <= 4: 2,
+#endif                   //    <= 8: 1); 2: the whole level loop above staging / ranges / hand-over; 3: staging and ranges above the level loop.  Measured: DESIGN.md section 9
 #ifndef HPB_LEAN
 #define HPB_LEAN 0       // 1: 20.3 KB of LDS instead of 22.9 (eight workgroups per CU): the key window shares its storage with the rounds' key words and is
 #endif                   //    re-read for the hand-over; level counters sized for the key type
@@ -669,13 +672,16 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     const u32 sub = blockIdx.x % HPQ_SUB;
     const TileList tl{ e_ir, e_b0, e_b1, e_b2, g0, ni };
 
+#if HPB_PRIO == 3
+    __builtin_amdgcn_s_setprio(2);
+#endif
     // ---- stage the block: leaves (SetupClusters :44-47, fused), keys -------------------------------------------------
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const u32 k = (u32)tid + (u32)i * NT;
         if (k < nleaf) {
             const u32 g = g0 + k, prim = svals[g];
-            const Box b = box_gather(boxes + prim);
+            const Box b = tris ? tri_box_gather(tris + (size_t)prim * 4) : box_gather(boxes + prim);
             float* f = reinterpret_cast<float*>(leaves + g);
             reinterpret_cast<u32*>(f)[0] = prim;
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
@@ -804,10 +810,18 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #endif
 
     // ---- local hierarchy, deepest level first; two tasks per wave pass ----------------------------------------------------
+#if HPB_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#elif HPB_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
     for (int lv = 0; lv < NLEV; ++lv) {
         const u32 c = s_cnt[lv];
         if (!c) continue;                            // block-uniform
         const u32 base = s_off[lv];
+#if HPB_PRIO == 1
+        if (c <= 2u) __builtin_amdgcn_s_setprio(3); else if (c <= 4u) __builtin_amdgcn_s_setprio(2); else if (c <= 8u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         for (u32 tw = (u32)wave * 2u; tw < c; tw += (u32)NW * 2u) {
             const u32 t = tw + (u32)half;
             const bool have = t < c;
@@ -838,6 +852,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         }
         __syncthreads();
     }
+#if HPB_PRIO == 1 || HPB_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (dbg == 3) return;
 #if HPB_LEAN
     // the rounds' key words overwrote the key window (every thread is past the level loop's last barrier): read it again for the hand-over
@@ -1185,7 +1202,7 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
     const int dbg = hploc_ablation();
     const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);
 #define HPB_LAUNCH(KK, TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<KK, TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
-                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg)
+                       (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg, (const float4*)sc.leaf_tris)
     { KernelScope ks(s, "k_hploc_block");
       if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC);
       else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, 6);

@@ -49,7 +49,10 @@ constexpr int SORT_BLOCK = 256;
 constexpr int SORT_IPT = BVH_SORT_IPT;                        // keys per thread
 constexpr int SORT_TILE = SORT_BLOCK * SORT_IPT;              // keys per workgroup (sizes the status rows)
 constexpr int SORT_IPT_WIDE = 20;                            // keys per thread for large inputs
-constexpr uint32_t SORT_WIDE_MIN_N = 1000000;
+#ifndef BVH_SORT_WIDE_MIN_N
+#define BVH_SORT_WIDE_MIN_N 1000000
+#endif
+constexpr uint32_t SORT_WIDE_MIN_N = BVH_SORT_WIDE_MIN_N;
 constexpr int SORT_MAX_PASSES = 8;                          // 8 digits: 64-bit keys
 static_assert(SORT_COUNTER_CLEAR >= SORT_MAX_PASSES, "the build path's first kernel clears the tile tickets of every pass");
 // The digit histograms exist in SORT_HIST_COPIES copies (copy c at hist + c * SORT_HIST_STRIDE): a producer workgroup flushes its counts
@@ -100,6 +103,8 @@ struct HplocScratch {
     uint64_t* queue_rng;     // u64[queue_capacity]
     uint32_t* queue_count;   // u32[64 * 32]          (one padded head per sub-queue)
     size_t    queue_capacity;
+    const void* leaf_tris = nullptr;   // build path, 64-byte triangles only: the emitters stage a leaf's box from its triangle (one aligned 64-byte line per
+                                       // leaf) instead of from the 24-byte box array (a box straddles two 64-byte lines one time in four); nullptr: boxes
 };
 size_t hploc_queue_capacity(uint32_t n);
 uint32_t hploc_block_tile();

@@ -25,6 +25,18 @@ static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit (k_onesweep: the f
 constexpr u32 ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 
 // interleaved {key, value} records of the intermediate passes: 8 bytes for u32 keys, 16 bytes {key, value, pad} for u64 keys
+// A/B switch (off): non-temporal key / value traffic of the passes (SORT_NT bit 0: tile loads, bit 1: scattered stores) — an attempt to keep the 240 MB
+// of primitive boxes in the 256 MiB Infinity Cache across the sort for the emitters' random gather.  Measured: see DESIGN.md section 9.
+#ifndef SORT_NT
+#define SORT_NT 0
+#endif
+#ifndef SORT_PRIO
+#define SORT_PRIO 0
+#endif
+template <typename T> __device__ __forceinline__ T sort_ld(const T* p) { if constexpr ((SORT_NT & 1) && sizeof(T) <= 8) return __builtin_nontemporal_load(p); else return *p; }
+template <typename T> __device__ __forceinline__ void sort_st(T* p, T v) { if constexpr ((SORT_NT & 2) && sizeof(T) <= 8) __builtin_nontemporal_store(v, p); else *p = v; }
+#define SORT_LD(P) sort_ld(P)
+#define SORT_ST(P, V) sort_st(P, V)
 template <typename K> struct PairRec;
 template <> struct PairRec<u32> {
     using type = u64;
@@ -113,6 +125,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #define SORT_STAMP() do { } while (0)
 #endif
     SORT_STAMP();                                    // 0: start
+#if SORT_PRIO
+    __builtin_amdgcn_s_setprio(3);                   // A/B switch (off): a tile runs at high priority until its digit totals are published (its successors wait for them)
+#endif
     // Tile id = workgroup id.  Decoupled look-back makes a tile wait for its predecessors' totals; with static ids that is only deadlock-free
     // if every predecessor is (or gets) resident, which HIP's dispatch order does not promise.  The usual cure — tile ids from an atomic
     // ticket — costs a returning atomic on ONE word per tile (~90 per us on this chip): the ~1000 workgroups that start together queued up to
@@ -146,11 +161,11 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         const u32 local = (u32)(wave * WAVE * IPT + i * WAVE + lane);
         const bool ok = local < valid;
         if (IN_AOS) {
-            const typename Rec::type kv = ok ? reinterpret_cast<const typename Rec::type*>(keys_in)[base + local] : Rec::pad();   // (a select, not a
+            const typename Rec::type kv = ok ? SORT_LD(reinterpret_cast<const typename Rec::type*>(keys_in) + base + local) : Rec::pad();   // (a select, not a
             key[i] = Rec::key(kv); val[i] = Rec::val(kv);                                   //  branch: the 16 loads stay in flight together)
         } else {
-            key[i] = ok ? keys_in[base + local] : ~(K)0;
-            val[i] = IOTA ? (base + local) : (ok ? vals_in[base + local] : 0u);
+            key[i] = ok ? SORT_LD(keys_in + base + local) : ~(K)0;
+            val[i] = IOTA ? (base + local) : (ok ? SORT_LD(vals_in + base + local) : 0u);
         }
     }
 #ifdef BVH_ABLATION
@@ -208,6 +223,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | total);
 #endif
     }
+#if SORT_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- exclusive scans over the 256 digits (wave scan + LDS hop), two in one: the tile's digit totals -> s_binoff, and the pass's
     // raw global digit counts -> gexcl (every tile redoes that 256-entry scan from L2: cheaper than a kernel launch per sort)
     u32 gexcl = 0;
@@ -318,8 +336,8 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         if (p < valid) {
             const K kk = s_keys[p];
             const u32 dst = (dbg & 2) ? base + p : s_gbase[(u32)(kk >> shift) & digit_mask] + p;
-            if (OUT_AOS) reinterpret_cast<typename Rec::type*>(keys_out)[dst] = Rec::pack(kk, s_vals[p]);
-            else { keys_out[dst] = kk; vals_out[dst] = s_vals[p]; }
+            if (OUT_AOS) SORT_ST(reinterpret_cast<typename Rec::type*>(keys_out) + dst, Rec::pack(kk, s_vals[p]));
+            else { SORT_ST(keys_out + dst, kk); SORT_ST(vals_out + dst, s_vals[p]); }
         }
     }
 #ifdef BVH_ABLATION
