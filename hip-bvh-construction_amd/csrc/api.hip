@@ -98,6 +98,24 @@ void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_sk
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return -(int)_e; } while (0)
 
+// The per-build read-backs (single-pass LBVH root index, PLOC++ iteration state) are 4-byte copies into pinned host words.  The host learns that one has
+// landed by polling the word itself (the caller stored `sentinel`, a value the device never writes, before enqueuing the copy): hipStreamSynchronize notices
+// the end of the stream ~6 us later than a poll of the word does (tools/probes/sync_latency.hip: 343.6 vs 337.7 us for eight launches + the copy) — 4 % of a
+// 262 144-triangle LBVH build.  The stream is in order, so everything enqueued before the copy is complete when the word changes.  The poll is bounded: after
+// ~4 M reads (several milliseconds: a build that long does not care) it falls back to hipStreamSynchronize, which also surfaces
+// an error of the stream.
+#ifndef BVH_POLL_READBACK
+#define BVH_POLL_READBACK 1
+#endif
+static int wait_readback(hipStream_t s, const u32* word, u32 sentinel) {
+#if BVH_POLL_READBACK
+    const volatile u32* w = word;
+    for (u32 polls = 0; polls < (1u << 22); ++polls) if (*w != sentinel) return 0;
+#endif
+    HIP_TRY(hipStreamSynchronize(s));
+    return *(const volatile u32*)word != sentinel ? 0 : BVH_E_INTERNAL;
+}
+
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Carver {
@@ -208,12 +226,17 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
         }
         ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh);
         fresh = false;
-        HIP_TRY(hipMemcpyAsync(host_state, sc.state, state_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        const u32 count = host_state[first + batch];
+        // two words come back: the iterations done so far, then the cluster count after this batch — the second copy is the one the host polls for
+        // (in-order stream: the first has landed when the second does); counts are < 2^30, the sentinel is not a count
+        u32* const h_iters = c->h_pinned + 1; u32* const h_count = c->h_pinned + 2;
+        *h_count = 0xFFFFFFFFu;
+        HIP_TRY(hipMemcpyAsync(h_iters, sc.state + 2 * PLOC_MAX_ITERS + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_count, sc.state + first + batch, 4, hipMemcpyDeviceToHost, c->stream));
+        { const int wr = wait_readback(c->stream, h_count, 0xFFFFFFFFu); if (wr) return wr; }
+        const u32 count = *h_count;
         if (count <= 1) {
-            c->ploc_last_n = n; c->ploc_last_iters = host_state[2 * PLOC_MAX_ITERS + 1];
-            if (iterations_out) *iterations_out = host_state[2 * PLOC_MAX_ITERS + 1];
+            c->ploc_last_n = n; c->ploc_last_iters = *h_iters;
+            if (iterations_out) *iterations_out = *h_iters;
             return 0;
         }
         first += batch; batch = 16;
@@ -421,7 +444,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     r = begin_emit(c); if (r) return r;
     launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, false, (int)c->options[BVH_OPT_LBVH_SCHEDULER]);
     r = end_emit(c); if (r) return r;
-    if (root_out) { HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); *root_out = c->h_pinned[0]; }
+    if (root_out) { c->h_pinned[0] = 0xFFFFFFFFu; HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, c->stream)); r = wait_readback(c->stream, c->h_pinned, 0xFFFFFFFFu); if (r) return r; *root_out = c->h_pinned[0]; }
     return 0;
 }
 
@@ -485,6 +508,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     prep.hist = c->sort.hist; prep.hist_words = (u32)SORT_HIST_COPIES * SORT_HIST_STRIDE;
     prep.status = reinterpret_cast<uint4*>(c->sort.status); prep.status_vecs = (u32)(((size_t)passes * sort_tiles(n) * SORT_RADIX) / 4);
     prep.counters = c->sort.counters; prep.extra = c->hploc.queue_count; prep.extra_words = 64 * 32;
+    if (algo == BVH_PLOCPP) ploc_begin_prep(c->ploc, n, prep);       // (the stage entry point bvh_emit_ploc launches k_ploc_init instead)
     const bool explicit_reset = !c->scene_ready;
     c->scene_ready = false;
     r = stage_extents_fmt(s, in, n, c->boxes, scene, explicit_reset, &prep); if (r) return r;
@@ -508,8 +532,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
                                   emit_hploc(c, s, c->boxes, c->skeys, key_bits, c->svals, n, c->nodes, c->leaves, true);
                                   c->hploc.leaf_tris = nullptr;
                                   out->d_leaves = c->leaves; out->layout = 1; break;
-        case BVH_PLOCPP:          ploc_begin(s, c->ploc, n);
-                                  r = run_ploc(c, n, c->nodes, c->leaves, c->boxes, c->svals, c->ploc, &ploc_iters); if (r) return r;
+        case BVH_PLOCPP:          r = run_ploc(c, n, c->nodes, c->leaves, c->boxes, c->svals, c->ploc, &ploc_iters); if (r) return r;
                                   out->d_leaves = c->leaves; out->layout = 1; break;
     }
     r = end_emit(c); if (r) return r;
@@ -517,8 +540,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (install.on) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
+        c->h_pinned[0] = 0xFFFFFFFFu;                                                      // (no node has this index: n < 2^30)
         HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, s));      // (pinned: a copy into pageable memory goes through a staging buffer)
-        HIP_TRY(hipStreamSynchronize(s));
+        r = wait_readback(s, c->h_pinned, 0xFFFFFFFFu); if (r) return r;
         out->root = c->h_pinned[0];
     }
     out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = scene;

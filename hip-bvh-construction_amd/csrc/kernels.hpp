@@ -21,7 +21,10 @@ struct KernelScope {
 constexpr int EM_BLOCK = 256;
 // what the build path's first kernel clears before it starts (the stand-alone sort entry point clears the same through sort_prepare / k_prepare)
 struct PrepArgs { uint32_t* hist = nullptr; uint32_t hist_words = 0; uint4* status = nullptr; uint32_t status_vecs = 0; uint32_t* counters = nullptr;
-                  uint32_t* extra = nullptr; uint32_t extra_words = 0; };
+                  uint32_t* extra = nullptr; uint32_t extra_words = 0;
+                  // PLOC++ builds: the iteration bookkeeping of ploc_begin (look-back status words of every iteration, state words with counts[0] = n)
+                  uint4* ploc_status = nullptr; uint32_t ploc_status_vecs = 0; uint64_t* ploc_tail = nullptr; uint32_t ploc_tail_words = 0;
+                  uint32_t* ploc_state = nullptr; uint32_t ploc_count = 0; };
 #ifdef BVH_ABLATION
 constexpr int SORT_COUNTER_CLEAR = 64;      // (+ the look-back statistics of the measurement build)
 #else
@@ -124,6 +127,7 @@ constexpr int PLOC_MAX_ITERS = 96;
 constexpr int PLOC_STATE_WORDS = 2 * PLOC_MAX_ITERS + 4;     // counts[MAX+1] | tickets[MAX] | iterations done
 inline uint32_t ploc_chunks(uint32_t n) { return (n + PLOC_CHUNK - 1) / PLOC_CHUNK; }
 void ploc_begin(hipStream_t s, const PlocScratch& sc, uint32_t n);
+void ploc_begin_prep(const PlocScratch& sc, uint32_t n, PrepArgs& prep);   // the same clearing as fields of the build path's first kernel (no launch)
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count);
 // fresh: iteration `first` is the build's very first one — it reads d_svals / d_boxes and writes d_leaves (SetupClusters fused)
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals,

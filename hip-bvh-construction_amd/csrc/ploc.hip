@@ -22,6 +22,12 @@ namespace bvh {
 #ifndef PLOC_DEFER
 #define PLOC_DEFER 1     // 0: walk and store right away (measured at 10 M: emit 2.42 ms instead of 2.00, 2 M: 0.79 instead of 0.75)
 #endif
+#ifndef PLOC_ONE_SHOT
+#define PLOC_ONE_SHOT 1
+#endif
+#ifndef PLOC_ONE_SHOT_MAX_N
+#define PLOC_ONE_SHOT_MAX_N (1 << 20)
+#endif
 #ifndef PLOC_ABL
 #define PLOC_ABL 0       // measurements only (tools/build_variant.sh): 1 no look-back wait, 2 no NN search, 3 no list stores — results are wrong
 #endif
@@ -349,6 +355,13 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
 #else
         finish(chunk, tot, ex, cid, pid, cb, mrg, keep);
 #endif
+#if PLOC_ONE_SHOT
+        // the grid covers the iteration's chunks (every late iteration): when no workgroup takes a second ticket the first `chunks` tickets go to
+        // `chunks` different workgroups, so nobody needs to ask again just to learn that the list is used up — the finish below starts a round trip earlier
+        // Measured on the MI355X (whole build, same box): Sponza-like 262 144 0.4107 -> 0.4065 ms, 524 288 0.5216 -> 0.5180, uniform 1 M 0.5630 -> 0.5605; but 2 M
+        // 0.783 -> 0.790 and 10 M 2.206 -> 2.245 (there the second ticket's round trip is what gives the predecessors time to publish before the walk): small inputs only
+        if (gridDim.x >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;              // (grid-uniform)
+#endif
     }
 #if PLOC_DEFER
     if (p_have) { __syncthreads(); finish(p_chunk, p_tot, p_ex, p_cid, p_pid, p_cb, p_mrg, p_keep); }
@@ -371,6 +384,13 @@ void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count
     const u32 vecs = (u32)(words / 2), tail = (u32)(words % 2);
     u32 blocks = (vecs + 255u) / 256u; if (blocks < 1u) blocks = 1u; if (blocks > 1024u) blocks = 1024u;
     hipLaunchKernelGGL(k_ploc_init, dim3(blocks), dim3(256), 0, s, sc.state, count, reinterpret_cast<uint4*>(sc.status), vecs, sc.status + (size_t)vecs * 2, tail);
+}
+void ploc_begin_prep(const PlocScratch& sc, uint32_t n, PrepArgs& prep) {
+    const size_t words = (size_t)PLOC_MAX_ITERS * ploc_chunks(n);
+    const u32 vecs = (u32)(words / 2), tail = (u32)(words % 2);
+    prep.ploc_status = reinterpret_cast<uint4*>(sc.status); prep.ploc_status_vecs = vecs;
+    prep.ploc_tail = sc.status + (size_t)vecs * 2; prep.ploc_tail_words = tail;
+    prep.ploc_state = sc.state; prep.ploc_count = n;
 }
 // enqueue iterations [first, first+count) of the current batch; parity = which id buffer iteration `first` reads.  The host does not
 // know the cluster count of an iteration; it only shapes the launch from a guess (C shrinks by ~20 % per iteration): any grid

@@ -60,6 +60,11 @@ __device__ __forceinline__ void prep_slice(const PrepArgs& p) {
     for (u32 i = t; i < p.hist_words; i += stride) p.hist[i] = 0u;
     for (u32 i = t; i < p.extra_words; i += stride) p.extra[i] = 0u;
     if (p.counters && t < (u32)SORT_COUNTER_CLEAR) p.counters[t] = 0u;
+    if (p.ploc_state) {                              // (block-uniform) PLOC++ build: what k_ploc_init clears
+        for (u32 i = t; i < p.ploc_status_vecs; i += stride) p.ploc_status[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (t < p.ploc_tail_words) p.ploc_tail[t] = 0ull;
+        if (t < (u32)PLOC_STATE_WORDS) p.ploc_state[t] = t == 0u ? p.ploc_count : 0u;
+    }
 }
 
 __global__ __launch_bounds__(EX_BLOCK) void k_extents(const float4* __restrict__ tris, bvh_aabb* __restrict__ boxes,
