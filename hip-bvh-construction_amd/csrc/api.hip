@@ -102,7 +102,7 @@ inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 // landed by polling the word itself (the caller stored `sentinel`, a value the device never writes, before enqueuing the copy): hipStreamSynchronize notices
 // the end of the stream ~6 us later than a poll of the word does (tools/probes/sync_latency.hip: 343.6 vs 337.7 us for eight launches + the copy) — 4 % of a
 // 262 144-triangle LBVH build.  The stream is in order, so everything enqueued before the copy is complete when the word changes.  The poll is bounded: after
-// ~4 M reads (several milliseconds: a build that long does not care) it falls back to hipStreamSynchronize, which also surfaces
+// ~4 M reads (some tens of milliseconds: a build that long does not care) it falls back to hipStreamSynchronize, which also surfaces
 // an error of the stream.
 #ifndef BVH_POLL_READBACK
 #define BVH_POLL_READBACK 1
@@ -110,7 +110,12 @@ inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 static int wait_readback(hipStream_t s, const u32* word, u32 sentinel) {
 #if BVH_POLL_READBACK
     const volatile u32* w = word;
-    for (u32 polls = 0; polls < (1u << 22); ++polls) if (*w != sentinel) return 0;
+    for (u32 polls = 0; polls < (1u << 22); ++polls) {
+        if (*w != sentinel) return 0;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();                      // (be a polite spinner: the runtime's helper threads may share this core)
+#endif
+    }
 #endif
     HIP_TRY(hipStreamSynchronize(s));
     return *(const volatile u32*)word != sentinel ? 0 : BVH_E_INTERNAL;

@@ -354,16 +354,22 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
+#ifndef EM_PPT
+#define EM_PPT 4         // primitives per thread of the grid-stride kernels below their workgroup caps (A/B: 2 / 1 measured at 262 144)
+#endif
+#ifndef EX_PPT
+#define EX_PPT 4
+#endif
 static inline int em_grid(u32 n) {
     // grid-stride kernels: ~4 primitives per thread up to 2048 workgroups (256 CUs x 8).  Every workgroup ends with global atomics on a
     // handful of addresses (6 scene-extent words; <= 1024 histogram bins), and one address takes ~90 atomics/us: at 262 k primitives
     // 1024 one-tile workgroups spent 11 us in that queue (k_extents 31 us, k_morton 23 us), 256 four-tile workgroups do not.
-    const u32 blocks = (n + 4 * EM_BLOCK - 1) / (4 * EM_BLOCK);
+    const u32 blocks = (n + EM_PPT * EM_BLOCK - 1) / (EM_PPT * EM_BLOCK);
     return (int)(blocks < 2048u ? (blocks ? blocks : 1u) : 2048u);
 }
 
 static inline int ex_grid(u32 n) {            // ~4 primitives per thread, at most 2 workgroups of 1024 threads per CU
-    const u32 blocks = (n + 4 * EX_BLOCK - 1) / (4 * EX_BLOCK);
+    const u32 blocks = (n + EX_PPT * EX_BLOCK - 1) / (EX_PPT * EX_BLOCK);
     return (int)(blocks < 512u ? (blocks ? blocks : 1u) : 512u);
 }
 
