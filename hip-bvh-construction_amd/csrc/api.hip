@@ -73,6 +73,7 @@ struct bvh_ctx {
     uint32_t ploc_last_n = 0, ploc_last_iters = 0;   // size and iteration count of the last PLOC++ build (run_ploc aims its first batch of launches at it)
     u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
+    uint32_t collapse_last_n = 0, collapse_last_levels = 0;   // levels the previous collapse of a tree of this size needed (first batch of launches)
     int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
 };
 
@@ -614,25 +615,37 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
     u32* state = c->ploc.state;                                         // >= COLLAPSE_STATE_WORDS words
     static_assert(PLOC_STATE_WORDS >= COLLAPSE_STATE_WORDS, "state scratch");
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[5], s));
-    collapse_begin(s, taskq, state, in->root);
-    u32 host[COLLAPSE_STATE_WORDS];
-    // wide levels ~ half the BVH2 depth: a first batch sized for a balanced tree, then batches of 16 until a level creates nothing
+    collapse_begin(s, taskq, state, in->root, true);
+    // a batch's level counts come back into pinned words (a copy into pageable memory goes through a staging buffer and blocks); the host polls a second,
+    // 4-byte copy of the batch's last count (in-order stream: the words before it have landed) instead of synchronising the stream — see wait_readback
+    u32* const host = c->h_pinned + 16; u32* const flag = c->h_pinned + 3;
+    static_assert(COLLAPSE_MAX_BATCH <= PLOC_STATE_WORDS, "pinned read-back words");
+    // wide levels ~ half the BVH2 depth: a first batch sized for a balanced tree — or one above what the previous collapse of a tree of this size needed
+    // (animation frames, the benchmark loop: a level launched after the end costs ~3 us) —, then batches of 16 until a level creates nothing
     int batch = 10; for (uint32_t m = n; m > 1u; m >>= 1) batch += 1;
-    bool first = true;
+    if (c->collapse_last_n == n && c->collapse_last_levels > 0) batch = (int)c->collapse_last_levels + 1;
+    if (batch > COLLAPSE_MAX_BATCH) batch = COLLAPSE_MAX_BATCH;
+    u32 base_begin = 0, base_len = 1, levels = 0;                      // the root task
     for (long long total = 0; total < (1ll << 31); total += batch, batch = 16) {
-        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, first, batch, n, (int)in->layout);
-        first = false;
+        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, base_begin, base_len, batch, n, (int)in->layout);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host, state, sizeof host, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (host[0] == host[2]) {                      // the last processed level allocated nothing
-            if (n_wide_out) *n_wide_out = host[0];
+        *flag = 0xFFFFFFFFu;
+        HIP_TRY(hipMemcpyAsync(host, state, (size_t)batch * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(flag, state + batch - 1, sizeof(u32), hipMemcpyDeviceToHost, s));
+        r = wait_readback(s, flag, 0xFFFFFFFFu); if (r) return r;
+        u32 len = base_len, allocated = base_begin + base_len;       // ids handed out so far
+        for (int l = 0; l < batch; ++l) { if (len) ++levels; len = host[l]; allocated += len; }
+        if (host[batch - 1] == 0u) {                   // the batch's last level allocated nothing: every later one would have no work
+            if (n_wide_out) *n_wide_out = allocated;
+            c->collapse_last_n = n; c->collapse_last_levels = levels;
             if (c->profiling) {   // token CollapseBvhTime (src/TwoPassLbvh.cpp:182), including this implementation's level read-backs
                 HIP_TRY(hipEventRecord(c->ev[6], s)); HIP_TRY(hipEventSynchronize(c->ev[6]));
                 HIP_TRY(hipEventElapsedTime(&c->last_collapse_ms, c->ev[5], c->ev[6]));
             }
             return 0;
         }
+        base_len = host[batch - 1]; base_begin = allocated - base_len;
+        collapse_begin(s, taskq, state, 0u, false);    // clear the counters for the next batch
     }
     return BVH_E_INTERNAL;
 }

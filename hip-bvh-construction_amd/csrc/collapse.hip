@@ -9,8 +9,8 @@
 //
 // The reference runs ONE launch in which every thread spins until its task appears (hangs unless all workgroups are
 // co-resident).  Here the wide tree is produced level by level: launch k processes the wide nodes
-// created by launch k-1 (a tiny snapshot kernel publishes the level bounds), ids are allocated with one block-aggregated
-// atomic per workgroup.  Numbering is allocation order (schedule dependent, as in the reference).  The host enqueues batches of
+// created by launch k-1 (every level counts what it allocates in a word of its own, so the next launch derives its bounds from finished
+// counts: no kernel in between), ids are allocated with one block-aggregated atomic per workgroup.  Numbering is allocation order (schedule dependent, as in the reference).  The host enqueues batches of
 // levels and reads the bounds back after each batch until a level created nothing: any depth works (a degenerate 1 M-leaf chain
 // just takes more batches).  A one-launch variant (waves taking 64-task batches from a ticket and polling their queue words) was
 // measured slower: 0.56 vs 0.30 ms at 262 k, 1.5 vs 1.2 ms at 10 M — a batch completes at the pace of its slowest task
@@ -26,17 +26,23 @@ static_assert(sizeof(Wide4) == 128 && sizeof(PrimNodeRec) == 8, "reference layou
 
 constexpr int CL_BLOCK = 256;
 
-// state: [0] allocation counter (next free wide id), [1] / [2] first wide id of the current / the next level, [3] levels that had work
-__global__ void k_collapse_init(uint2* taskq, u32* state, u32 root) {
-    if (threadIdx.x == 0) { taskq[0] = make_uint2(root, INV); state[0] = 1; state[1] = 0; state[2] = 1; state[3] = 0; }   // src/TwoPassLbvh.cpp:160-167
+// Level bounds without a kernel in between (round 3; rounds 1-2 ran a one-thread snapshot kernel after every level: twice the launches).  A batch of levels
+// shares state[0 .. COLLAPSE_MAX_BATCH): state[l] = wide nodes allocated BY level l of the batch, all zero when the batch starts.  Level l works on the
+// ids [begin_l, end_l): begin_0 / end_0 come from the host (the root task, or what the previous batch's read-back says), begin_l = end_(l-1),
+// end_l = begin_l + state[l-1] — every count a launch reads was finished by an earlier launch — and it allocates id = end_l + atomicAdd(&state[l], count).
+__global__ void k_collapse_init(uint2* taskq, u32* state, u32 root, int with_root) {
+    if (with_root && threadIdx.x == 0) taskq[0] = make_uint2(root, INV);                      // src/TwoPassLbvh.cpp:160-167
+    for (int i = threadIdx.x; i < COLLAPSE_MAX_BATCH; i += blockDim.x) state[i] = 0u;
 }
-// between two levels: the wide nodes the last level allocated are the next level
-__global__ void k_collapse_snapshot(u32* state) { if (threadIdx.x == 0) { if (state[2] > state[1]) state[3] += 1; state[1] = state[2]; state[2] = state[0]; } }
 
 __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __restrict__ nodes, const bvh_primref* __restrict__ leaves,
                                                              Wide4* __restrict__ wide, PrimNodeRec* __restrict__ prims, uint2* taskq,
-                                                             u32* state, u32 n, int layout) {
-    const u32 begin = state[1], end = state[2];
+                                                             u32* state, u32 n, int layout, u32 base_begin, u32 base_len, int level) {
+    u32 begin = base_begin, len = base_len;
+    for (int j = 0; j < level; ++j) { begin += len; len = state[j]; }        // (uniform; <= COLLAPSE_MAX_BATCH cached words)
+    const u32 end = begin + len;
+    if (len == 0u) return;
+    u32* const alloc = state + level;
     const u32 ni = n - 1;
     __shared__ u32 s_base, s_count;
     auto box_of = [&](u32 c) -> Box { return (layout == 1 && c >= ni) ? box_load_u(&leaves[c - ni].aabb) : box_load(&nodes[c].aabb); };
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __
         u32 my_off = 0;
         if (n_int) my_off = atomicAdd(&s_count, n_int);
         __syncthreads();
-        if (threadIdx.x == 0) s_base = s_count ? atomicAdd(&state[0], s_count) : 0u;
+        if (threadIdx.x == 0) s_base = s_count ? end + atomicAdd(alloc, s_count) : 0u;
         __syncthreads();
         if (have) {
             Wide4 w;
@@ -100,19 +106,18 @@ __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __
     }
 }
 
-void collapse_begin(hipStream_t s, uint2* d_taskq, u32* d_state, u32 root) {
-    hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(64), 0, s, d_taskq, d_state, root);
+// with_root: the collapse starts (the root task is queued); otherwise only the batch's counters are cleared for the next batch
+void collapse_begin(hipStream_t s, uint2* d_taskq, u32* d_state, u32 root, bool with_root) {
+    hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(64), 0, s, d_taskq, d_state, root, with_root ? 1 : 0);
 }
-// enqueue `count` more levels (a level without work returns at once); `first`: the very first level follows collapse_begin directly
+// enqueue the `count` levels of one batch (a level without work returns at once); the batch's first level works on [base_begin, base_begin + base_len)
 void collapse_enqueue(hipStream_t s, const void* d_nodes, const void* d_leaves, void* d_wide, void* d_prims, uint2* d_taskq,
-                      u32* d_state, bool first, int count, u32 n, int layout) {
+                      u32* d_state, u32 base_begin, u32 base_len, int count, u32 n, int layout) {
     u32 grid = (n / 2 + CL_BLOCK - 1) / CL_BLOCK; if (grid > 2048u) grid = 2048u; if (grid == 0) grid = 1;
     KernelScope ks(s, "k_collapse_level");
-    for (int level = 0; level < count; ++level) {
-        if (!(first && level == 0)) hipLaunchKernelGGL(k_collapse_snapshot, dim3(1), dim3(64), 0, s, d_state);
+    for (int level = 0; level < count; ++level)
         hipLaunchKernelGGL(k_collapse_level, dim3(grid), dim3(CL_BLOCK), 0, s, (const bvh2_node*)d_nodes, (const bvh_primref*)d_leaves,
-                           (Wide4*)d_wide, (PrimNodeRec*)d_prims, d_taskq, d_state, n, layout);
-    }
+                           (Wide4*)d_wide, (PrimNodeRec*)d_prims, d_taskq, d_state, n, layout, base_begin, base_len, level);
 }
 
 } // namespace bvh
