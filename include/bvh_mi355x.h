@@ -232,7 +232,10 @@ int  bvh_batch_build(bvh_batch* batch, bvh_algo algo, const void* const* h_tris,
 void bvh_batch_destroy(bvh_batch* batch);
 
 /* wait for everything enqueued on the ctx's stream (bvh_build is asynchronous unless it has to read something back:
- * profiling on, single-pass root index, PLOC++ iteration batches) */
+ * profiling on, single-pass root index, PLOC++ iteration batches, collapse level counts; those read-backs are 4-byte
+ * copies into pinned host words behind the build's launches on the in-order stream, and the call returns once the word
+ * has landed — the host polls it, which notices the end of the build a few microseconds before hipStreamSynchronize does —
+ * i.e. when every launch of the build has completed) */
 int  bvh_ctx_synchronize(bvh_ctx* ctx);
 
 /* plain device-memory helpers so that hosts without a HIP binding (ctypes, cgo, JNI ...) can stage buffers */
