@@ -36,7 +36,7 @@ KERNEL_BYTES_PER_PRIM = {
     "k_extents": 88.0,            # R Triangle 64 + W Aabb 24
     "k_morton": 32.0,             # R Aabb 24 + W key 4 + W val 4   (this build: 28, value is implicit)
     "k_onesweep": 17.0,           # per pass: R 8 + W 8 (+ hist R 4 amortised over 4 passes)
-    "k_hploc": 198.0,             # one-launch HPLOC (n < 1 M): SetupClusters 64 + HPloc 134 (keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32)
+    "k_hploc": 198.0,             # one-launch HPLOC (n < 800 k): SetupClusters 64 + HPloc 134 (keys 4 + parent xchg 16 + cluster id L/S 18.3 + AABB loads 63.9 + W node 32)
     "k_hploc_block": 177.9,       # block-local kernel: SetupClusters 64 + 85 % of HPloc's 134 (the merge tasks whose range lies inside a 512-leaf tile)
     "k_hploc_ext": 20.1,          # the other 15 % of the merge tasks (ranges crossing tiles)
     "k_lbvh_single": 224.0,

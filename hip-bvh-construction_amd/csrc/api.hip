@@ -80,8 +80,9 @@ struct bvh_ctx {
 namespace {
 
 // HPLOC: one asynchronous launch below this size, LDS-tiled block kernel + external climb above (measured on MI355X: 1122 vs 966
-// Mtris/s at 262 k, 3005 vs 3416 at 2 M, 3848 vs 5616 at 10 M)
-constexpr uint32_t HPLOC_BLOCK_MIN_N = 1000000;
+// Mtris/s at 262 k, 3005 vs 3416 at 2 M, 3848 vs 5616 at 10 M; whole build, one launch / tiles, end of round 3 (tools/ab_sched_small.py):
+// 400 k 0.1928 / 0.2302 ms, 600 k 0.2134 / 0.2234, 900 k 0.2603 / 0.2511)
+constexpr uint32_t HPLOC_BLOCK_MIN_N = 800000;
 inline bool hploc_use_block(const bvh_ctx* c, uint32_t n) {
     if (n <= 2 * hploc_block_tile()) return false;     // the root must cross tiles
     const int64_t o = c->options[BVH_OPT_HPLOC_SCHEDULER];   // 1 async / 2 tiles: the host's override (A/B measurements, tests)

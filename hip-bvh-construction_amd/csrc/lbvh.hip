@@ -289,7 +289,8 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u3
 // ---- launchers ---------------------------------------------------------------------------------------------------
 // key_bits: 32 = u32 keys (the reference's 30-bit codes), 64 = u64 keys (60-bit codes).  d_slots: u64[n], all-zero (kept clean by the
 // protocol).  Large inputs: tile kernel + external climb; d_queue: uint4[queue_capacity], d_queue_count: u32[64 * 32 + 1].
-constexpr uint32_t LBVH_BLOCK_MIN_N = 300000;      // below: one launch (k_lbvh_single / k_refit); measured crossover ~262 k (350 k: emit 0.057 vs 0.052 ms, 450 k: 0.068 vs 0.056)
+constexpr uint32_t LBVH_BLOCK_MIN_N = 240000;      // below: one launch (k_lbvh_single / k_refit).  Whole single-pass build, one launch / tiles (tools/ab_sched_small.py, end of round 3):
+                                                   // 150 k 0.1022 / 0.1074 ms, 200 k 0.1081 / 0.1104, Sponza-like 262 144 0.1175 / 0.1147, uniform 262 144 0.1136 / 0.1112, 400 k 0.1339 / 0.1285
 size_t lbvh_queue_capacity(uint32_t n) { return (((size_t)n / LBVH_TILE + 1) / LBQ_SUB + 2) * LBVH_TILE * LBQ_SUB; }   // every tile may queue T roots
 static bool lbvh_use_tiles(uint32_t n, int scheduler) {   // scheduler: BVH_OPT_LBVH_SCHEDULER (1 one-launch kernels, 2 tiles: the host's override)
     return scheduler == 2 ? true : scheduler == 1 ? false : n >= LBVH_BLOCK_MIN_N;
