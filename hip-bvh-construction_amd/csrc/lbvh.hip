@@ -300,7 +300,10 @@ static void launch_lbvh_tiles(hipStream_t s, const void* d_boxes, const void* d_
                               uint64_t* d_slots, uint32_t* d_root, void* d_queue, size_t queue_capacity, uint32_t* d_queue_count, bool heads_cleared, bool karras) {
     (void)queue_capacity; (void)d_queue_count; (void)heads_cleared;   // (every tile owns a segment of the queue: no heads to clear)
     const u32 ntiles = (n + LBVH_TILE - 1) / LBVH_TILE;
-    u32 slot_shift = 5;                                 // lanes per tile segment in k_lbvh_ext: as many as keep every thread resident (<= 400 k threads), 8..32
+#ifndef LBVH_EXT_MAX_SHIFT
+#define LBVH_EXT_MAX_SHIFT 5
+#endif
+    u32 slot_shift = LBVH_EXT_MAX_SHIFT;                // lanes per tile segment in k_lbvh_ext: as many as keep every thread resident (<= 400 k threads), 8..32
     while (slot_shift > 3 && ((size_t)ntiles << slot_shift) > 400000u) --slot_shift;
     const u32 eb = ((ntiles << slot_shift) + LBVH_BLOCK - 1) / LBVH_BLOCK;
     const dim3 gt(ntiles), bt(LBVH_TILE), ge(eb < 4096u ? eb : 4096u), be(LBVH_BLOCK);
