@@ -89,7 +89,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys,
 // 262 k 0.054 -> 0.050 -> 0.049, 900 k 0.078 -> 0.073 -> 0.072).
 constexpr int SORT_NARROW_NT = 1024, SORT_NARROW_IPT = SORT_TILE / 1024;
 static_assert(SORT_NARROW_NT * SORT_NARROW_IPT == SORT_TILE, "the status rows are sized for SORT_TILE-pair tiles");
-template <typename K> struct SortWide { static constexpr int NT = 512, IPT = 13; };
+#ifndef SORT_WIDE_IPT
+#define SORT_WIDE_IPT 13
+#endif
+template <typename K> struct SortWide { static constexpr int NT = 512, IPT = SORT_WIDE_IPT; };
 template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };    // 5120-pair tiles, 68 KB: 8 passes at 10 M 0.656 (256 x 20) -> 0.610 ms; 512 x 8: 0.657, 512 x 12: 0.731
 #ifndef SORT_EARLY_PUBLISH
 #define SORT_EARLY_PUBLISH 0     // 1: the totals go out before the ranking (A/B switch; measured slower, see the comment at its use)
