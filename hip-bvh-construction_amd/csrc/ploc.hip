@@ -22,6 +22,9 @@ namespace bvh {
 #ifndef PLOC_DEFER
 #define PLOC_DEFER 1     // 0: walk and store right away (measured at 10 M: emit 2.42 ms instead of 2.00, 2 M: 0.79 instead of 0.75)
 #endif
+#ifndef PLOC_TAIL_PAIRS
+#define PLOC_TAIL_PAIRS 1
+#endif
 #ifndef PLOC_ONE_SHOT
 #define PLOC_ONE_SHOT 1
 #endif
@@ -174,6 +177,41 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         } else entry_load(list_in, g, id, b);
     };
 
+    // (lo, hi: first valid span entry, one past the last; the tail below runs it on the whole list, lo = 0)
+    auto nn_pairs = [&](const int lo, const int hi) {
+        // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270).  As the reference does it:
+        // every pair (s, s + r), r = 1..8, is evaluated ONCE and minimised as {area bits, other position} into both ends' words (LDS atomics).  A
+        // 16-lane DPP row holds 32 consecutive span entries, two per lane, and evaluates the pairs of its first 24 (common.hpp, row_shl): the
+        // boxes are read from LDS once (round 1 read the 16 neighbours of every entry: 192 LDS reads per cluster, the limiter of the mid-size iterations).
+        {
+            constexpr int ROWS = PL_BLOCK / 16, TILES = (PL_HALO + PLOC_CHUNK + PL_RADIUS + 23) / 24;     // pairs with s in [0, 1048)
+            static_assert(TILES % 4 == 0 || TILES <= ROWS, "whole waves per pass");
+            const int row = tid >> 4, rl = tid & 15;
+            for (int t = row; t < TILES && 24 * t < hi; t += ROWS) {
+                const int sA = 24 * t + 2 * rl, sB = sA + 1;
+                const Box bA = (sA >= lo && sA < hi) ? lds_box(s, sA) : box_empty(), bB = (sB >= lo && sB < hi) ? lds_box(s, sB) : box_empty();
+                const int limA = (rl < 12 && sA >= lo) ? hi - sA : 0, limB = (rl < 12 && sB >= lo) ? hi - sB : 0;   // pair (s, s + r) exists iff r < lim
+                auto cand = [&](const Box& nA, const Box& nB, const int r) {
+                    const v2f_t lx = { fminf(nA.lx, bA.lx), fminf(nB.lx, bB.lx) }, ly = { fminf(nA.ly, bA.ly), fminf(nB.ly, bB.ly) }, lz = { fminf(nA.lz, bA.lz), fminf(nB.lz, bB.lz) };
+                    const v2f_t hx = { fmaxf(nA.hx, bA.hx), fmaxf(nB.hx, bB.hx) }, hy = { fmaxf(nA.hy, bA.hy), fmaxf(nB.hy, bB.hy) }, hz = { fmaxf(nA.hz, bA.hz), fmaxf(nB.hz, bB.hz) };
+                    const v2f_t area = area_pair(lx, ly, lz, hx, hy, hz);
+                    const unsigned long long kA = (unsigned long long)__float_as_uint(area.x) << 32, kB = (unsigned long long)__float_as_uint(area.y) << 32;
+                    if (r < limA) {
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA + r), kA | (u32)sA);
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA), kA | (u32)(sA + r));
+                    }
+                    if (r < limB) {
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB + r), kB | (u32)sB);
+                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB), kB | (u32)(sB + r));
+                    }
+                };
+                cand(bB, row_shl<1>(bA), 1);               cand(row_shl<1>(bA), row_shl<1>(bB), 2);
+                cand(row_shl<1>(bB), row_shl<2>(bA), 3);   cand(row_shl<2>(bA), row_shl<2>(bB), 4);
+                cand(row_shl<2>(bB), row_shl<3>(bA), 5);   cand(row_shl<3>(bA), row_shl<3>(bB), 6);
+                cand(row_shl<3>(bB), row_shl<4>(bA), 7);   cand(row_shl<4>(bA), row_shl<4>(bB), 8);
+            }
+        }
+    };
     if (C < (u32)PLOC_CHUNK) {
         // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
         if (blockIdx.x != 0) return;
@@ -182,8 +220,15 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         u32 c = C;
         while (c > 1) {
             if (c <= (u32)WAVE) { if (tid < WAVE) ploc_tail_wave(s, c, nodes, tid); break; }         // (block-uniform; the list in LDS is complete: barrier above / at the loop's end)
+#if PLOC_TAIL_PAIRS
+            for (int k = tid; k < (int)c + PL_RADIUS; k += PL_BLOCK) s.nn[k] = ~0ull;               // :131-148, range clipped to [0,c): every pair once, as in the
+            __syncthreads();                                                                        // iterations (nearest() reads 16 neighbour boxes per cluster from LDS)
+            nn_pairs(0, (int)c);
+            __syncthreads();
+#else
             for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = (u64)nearest(s, k, 0, (int)c);   // :131-148, range clipped to [0,c)
             __syncthreads();
+#endif
             // each thread owns PL_CPT consecutive list positions
             u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
             u32 packed = 0;
@@ -294,38 +339,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         __syncthreads();
         const int lo = (int)(o - PL_HALO < 0 ? PL_HALO - o : 0);                                   // first valid span entry
         const int hi = (int)((long long)C - (o - PL_HALO) < PL_SPAN ? (long long)C - (o - PL_HALO) : PL_SPAN);   // one past the last valid
-        // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270).  As the reference does it:
-        // every pair (s, s + r), r = 1..8, is evaluated ONCE and minimised as {area bits, other position} into both ends' words (LDS atomics).  A
-        // 16-lane DPP row holds 32 consecutive span entries, two per lane, and evaluates the pairs of its first 24 (common.hpp, row_shl): the
-        // boxes are read from LDS once (round 1 read the 16 neighbours of every entry: 192 LDS reads per cluster, the limiter of the mid-size iterations).
-        {
-            constexpr int ROWS = PL_BLOCK / 16, TILES = (PL_HALO + PLOC_CHUNK + PL_RADIUS + 23) / 24;     // pairs with s in [0, 1048)
-            static_assert(TILES % 4 == 0 || TILES <= ROWS, "whole waves per pass");
-            const int row = tid >> 4, rl = tid & 15;
-            for (int t = row; t < TILES; t += ROWS) {
-                const int sA = 24 * t + 2 * rl, sB = sA + 1;
-                const Box bA = (sA >= lo && sA < hi) ? lds_box(s, sA) : box_empty(), bB = (sB >= lo && sB < hi) ? lds_box(s, sB) : box_empty();
-                const int limA = (rl < 12 && sA >= lo) ? hi - sA : 0, limB = (rl < 12 && sB >= lo) ? hi - sB : 0;   // pair (s, s + r) exists iff r < lim
-                auto cand = [&](const Box& nA, const Box& nB, const int r) {
-                    const v2f_t lx = { fminf(nA.lx, bA.lx), fminf(nB.lx, bB.lx) }, ly = { fminf(nA.ly, bA.ly), fminf(nB.ly, bB.ly) }, lz = { fminf(nA.lz, bA.lz), fminf(nB.lz, bB.lz) };
-                    const v2f_t hx = { fmaxf(nA.hx, bA.hx), fmaxf(nB.hx, bB.hx) }, hy = { fmaxf(nA.hy, bA.hy), fmaxf(nB.hy, bB.hy) }, hz = { fmaxf(nA.hz, bA.hz), fmaxf(nB.hz, bB.hz) };
-                    const v2f_t area = area_pair(lx, ly, lz, hx, hy, hz);
-                    const unsigned long long kA = (unsigned long long)__float_as_uint(area.x) << 32, kB = (unsigned long long)__float_as_uint(area.y) << 32;
-                    if (r < limA) {
-                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA + r), kA | (u32)sA);
-                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA), kA | (u32)(sA + r));
-                    }
-                    if (r < limB) {
-                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB + r), kB | (u32)sB);
-                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB), kB | (u32)(sB + r));
-                    }
-                };
-                cand(bB, row_shl<1>(bA), 1);               cand(row_shl<1>(bA), row_shl<1>(bB), 2);
-                cand(row_shl<1>(bB), row_shl<2>(bA), 3);   cand(row_shl<2>(bA), row_shl<2>(bB), 4);
-                cand(row_shl<2>(bB), row_shl<3>(bA), 5);   cand(row_shl<3>(bA), row_shl<3>(bB), 6);
-                cand(row_shl<3>(bB), row_shl<4>(bA), 7);   cand(row_shl<4>(bA), row_shl<4>(bB), 8);
-            }
-        }
+        nn_pairs(lo, hi);
         __syncthreads();
         u32 cid[PL_CPT]; Box cb[PL_CPT]; bool mrg[PL_CPT], keep[PL_CPT]; u32 pid[PL_CPT];
         u32 packed = 0;
