@@ -221,7 +221,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         while (c > 1) {
             if (c <= (u32)WAVE) { if (tid < WAVE) ploc_tail_wave(s, c, nodes, tid); break; }         // (block-uniform; the list in LDS is complete: barrier above / at the loop's end)
 #if PLOC_TAIL_PAIRS
-            for (int k = tid; k < (int)c + PL_RADIUS; k += PL_BLOCK) s.nn[k] = ~0ull;               // :131-148, range clipped to [0,c): every pair once, as in the
+            for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = ~0ull;                             // :131-148, range clipped to [0,c): every pair once, as in the
             __syncthreads();                                                                        // iterations (nearest() reads 16 neighbour boxes per cluster from LDS)
             nn_pairs(0, (int)c);
             __syncthreads();
