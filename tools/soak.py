@@ -9,8 +9,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIZES = [2, 3, 17, 33, 511, 513, 1025, 2100, 40_000, 262_144, 500_001, 1_000_003, 2_345_678, 8_100_000]
-# sizes straddling the scheduler thresholds: LBVH tiles from 300 k, HPLOC tiles and wide sort tiles from 1 M, ticketed external climb from 8 M
-THRESHOLD_SIZES = [299_999, 300_000, 300_001, 999_999, 1_000_000, 1_000_001, 7_999_999, 8_000_000]
+# sizes straddling the scheduler thresholds: LBVH tiles from 240 k, HPLOC tiles from 800 k, wide sort tiles from 1 M, one-shot PLOC++ tickets below 2^20, ticketed external climb from 8 M
+THRESHOLD_SIZES = [239_999, 240_000, 240_001, 799_999, 800_000, 800_001, 999_999, 1_000_000, 1_000_001, 1_048_575, 1_048_576, 1_048_577, 7_999_999, 8_000_000]
 
 
 def soak(pkg, orc, ctx, budget: float, seed: int, sizes=SIZES, max_random: int = 3_000_000, log=print):
