@@ -74,6 +74,8 @@ struct bvh_ctx {
     u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
     uint32_t collapse_last_n = 0, collapse_last_levels = 0;   // levels the previous collapse of a tree of this size needed (first batch of launches)
+    uint32_t collapse_last_len[COLLAPSE_MAX_BATCH] = {0};     // ... and their task counts (grid sizes of the first batch's launches),
+    int collapse_len_batch = 0;                               //     valid for that many levels (0: the previous collapse took several batches)
     int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
 };
 
@@ -628,17 +630,23 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
     if (batch > COLLAPSE_MAX_BATCH) batch = COLLAPSE_MAX_BATCH;
     u32 base_begin = 0, base_len = 1, levels = 0;                      // the root task
     for (long long total = 0; total < (1ll << 31); total += batch, batch = 16) {
-        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, base_begin, base_len, batch, n, (int)in->layout);
+        const bool known = total == 0 && c->collapse_last_n == n && c->collapse_len_batch > 0 && batch <= c->collapse_len_batch + 1;
+        collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, base_begin, base_len, batch, n, (int)in->layout,
+                         known ? c->collapse_last_len : nullptr);
         HIP_TRY(hipGetLastError());
         *flag = 0xFFFFFFFFu;
         HIP_TRY(hipMemcpyAsync(host, state, (size_t)batch * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(flag, state + batch - 1, sizeof(u32), hipMemcpyDeviceToHost, s));
         r = wait_readback(s, flag, 0xFFFFFFFFu); if (r) return r;
         u32 len = base_len, allocated = base_begin + base_len;       // ids handed out so far
-        for (int l = 0; l < batch; ++l) { if (len) ++levels; len = host[l]; allocated += len; }
+        u32 lens[COLLAPSE_MAX_BATCH + 1]; lens[0] = base_len;
+        for (int l = 0; l < batch; ++l) { if (len) ++levels; len = host[l]; allocated += len; lens[l + 1] = len; }
         if (host[batch - 1] == 0u) {                   // the batch's last level allocated nothing: every later one would have no work
             if (n_wide_out) *n_wide_out = allocated;
+            // (remembered only when the whole collapse was one batch: then level l of the next first batch is level l of this one)
             c->collapse_last_n = n; c->collapse_last_levels = levels;
+            c->collapse_len_batch = 0;
+            if (total == 0) { c->collapse_len_batch = batch; for (int l = 0; l < COLLAPSE_MAX_BATCH; ++l) c->collapse_last_len[l] = l < batch ? lens[l] : 0u; }
             if (c->profiling) {   // token CollapseBvhTime (src/TwoPassLbvh.cpp:182), including this implementation's level read-backs
                 HIP_TRY(hipEventRecord(c->ev[6], s)); HIP_TRY(hipEventSynchronize(c->ev[6]));
                 HIP_TRY(hipEventElapsedTime(&c->last_collapse_ms, c->ev[5], c->ev[6]));

@@ -112,12 +112,17 @@ void collapse_begin(hipStream_t s, uint2* d_taskq, u32* d_state, u32 root, bool 
 }
 // enqueue the `count` levels of one batch (a level without work returns at once); the batch's first level works on [base_begin, base_begin + base_len)
 void collapse_enqueue(hipStream_t s, const void* d_nodes, const void* d_leaves, void* d_wide, void* d_prims, uint2* d_taskq,
-                      u32* d_state, u32 base_begin, u32 base_len, int count, u32 n, int layout) {
-    u32 grid = (n / 2 + CL_BLOCK - 1) / CL_BLOCK; if (grid > 2048u) grid = 2048u; if (grid == 0) grid = 1;
+                      u32* d_state, u32 base_begin, u32 base_len, int count, u32 n, int layout, const u32* expect) {
+    u32 full = (n / 2 + CL_BLOCK - 1) / CL_BLOCK; if (full > 2048u) full = 2048u; if (full == 0) full = 1;
     KernelScope ks(s, "k_collapse_level");
-    for (int level = 0; level < count; ++level)
+    for (int level = 0; level < count; ++level) {
+        // expect[level]: the tasks this level had in the previous collapse of a tree of this size (nullptr: unknown) — most levels of a wide tree are thin,
+        // and a launch of hundreds of workgroups that find nothing costs more than the level's work; any grid is correct (grid-stride loop)
+        u32 grid = full;
+        if (expect) { const u32 want = (expect[level] + expect[level] / 4u + (u32)CL_BLOCK - 1u) / (u32)CL_BLOCK + 1u; if (want < grid) grid = want; }
         hipLaunchKernelGGL(k_collapse_level, dim3(grid), dim3(CL_BLOCK), 0, s, (const bvh2_node*)d_nodes, (const bvh_primref*)d_leaves,
                            (Wide4*)d_wide, (PrimNodeRec*)d_prims, d_taskq, d_state, n, layout, base_begin, base_len, level);
+    }
 }
 
 } // namespace bvh

@@ -138,7 +138,8 @@ constexpr int COLLAPSE_MAX_BATCH = 64;                       // levels per batch
 constexpr int COLLAPSE_STATE_WORDS = COLLAPSE_MAX_BATCH;
 void collapse_begin(hipStream_t s, uint2* d_taskq, uint32_t* d_state, uint32_t root, bool with_root);
 void collapse_enqueue(hipStream_t s, const void* d_nodes, const void* d_leaves, void* d_wide, void* d_prims, uint2* d_taskq,
-                      uint32_t* d_state, uint32_t base_begin, uint32_t base_len, int count, uint32_t n, int layout);
+                      uint32_t* d_state, uint32_t base_begin, uint32_t base_len, int count, uint32_t n, int layout,
+                      const uint32_t* expect = nullptr /* count words: the levels' task counts of the previous same-size collapse (grid sizing only) */);
 
 // ---- consumer side (trace.hip)
 void launch_generate_rays(hipStream_t s, const void* d_cam, void* d_rays, uint32_t width, uint32_t height);
