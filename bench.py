@@ -168,14 +168,22 @@ def main() -> None:
     # Per-kernel HIP events are recorded on the launch stream INSIDE the timed region, for every 8th build (an event between two launches
     # costs a few microseconds of launch gap — one per launch of every build stretched a 1.42 ms build to 1.50): the kernels' average launch
     # durations and the roofline come from those sampled builds of the timed region.
+    # The sampling phase is chosen so that the timed region's FIRST build is not a sampled one: the build right after the barrier's idle gap runs a few per cent
+    # slower (clocks), and with a short timed region (--steps 20: two or three samples) it would be a third of the kernels' averages.  The last `phase` of the W
+    # warm-up builds therefore run with the recorder already on (the library samples builds 0, 8, 16, ... after set_profiling); what they record is subtracted.
     ctx.set_profiling(0)
-    for _ in range(args.warmup):
+    sample_every = 1 if args.steps < 16 else 8
+    phase = 0 if (sample_every == 1 or args.no_kernel_events) else min(args.warmup, sample_every // 2)
+    for _ in range(args.warmup - phase):
         step()
     barrier()
-    sample_every = 1 if args.steps < 16 else 8
-    n_sampled = (args.steps + sample_every - 1) // sample_every
     if not args.no_kernel_events:
         ctx.set_kernel_sampling(sample_every); ctx.set_profiling(2)
+    for _ in range(phase):
+        step()
+    barrier()
+    ktimes_warm = ctx.kernel_times() if phase else {}
+    n_sampled = sum(1 for i in range(phase, phase + args.steps) if i % sample_every == 0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -187,6 +195,8 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()
+    if ktimes_warm:        # (the warm-up builds that ran with the recorder on)
+        ktimes = {k: (v[0] - ktimes_warm.get(k, (0.0, 0))[0], v[1] - ktimes_warm.get(k, (0.0, 0))[1]) for k, v in ktimes.items()}
     # all-gather of the root boxes: mean / max over the timed steps on this rank, device time incl. the 24-byte staging copy
     gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_events[-args.steps:]] if gather_events else []
     if gather and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
@@ -260,7 +270,7 @@ def main() -> None:
                    "seed": "1+rank", "parallelism": f"scene-shard x{world}" + (" + allgather(root aabb)" if world > 1 else "")},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "kernel_ms_per_step": {k: round(v[0] / n_sampled, 4) for k, v in ktimes.items()},     # from the sampled builds of the timed region
-        "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds",
+        "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds" + (f" ({n_sampled} builds, the first one at timed build {(-phase) % sample_every})" if sample_every > 1 else ""),
         "sah_bvh2": round(sah, 4),
         "pipeline_roofline": {"algorithmic_bytes": pipeline_bytes, "source": ("exact: " + ex[3]) if ex else "SURVEY.md 8(d) constants (bvh_timings.bytes_algorithmic)",
                               "achieved_GBs": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
