@@ -60,7 +60,7 @@ ALGO_NAMES = {0: "TwoPassLbvh", 1: "SinglePassLbvh", 2: "PLOCNew", 3: "HPLOC"}
 EXPORTS = [
     "bvh_ctx_create", "bvh_ctx_create_on_stream", "bvh_ctx_destroy", "bvh_ctx_reserve", "bvh_ctx_device", "bvh_ctx_stream",
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_build_ex", "bvh_stage_extents", "bvh_stage_extents_ex",
-    "bvh_stage_morton", "bvh_stage_morton64", "bvh_sort_pairs", "bvh_sort_pairs64",
+    "bvh_stage_morton", "bvh_stage_morton64", "bvh_stage_morton_plan", "bvh_sort_pairs", "bvh_sort_pairs64",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_trace", "bvh_sah_cost",
     "bvh_ctx_set_kernel_filter", "bvh_ctx_set_kernel_sampling", "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_destroy",
     "bvh_ctx_set_option", "bvh_ctx_get_option", "bvh_abi_version", "bvh_abi_struct_sizes",
@@ -96,7 +96,7 @@ ABI_VERSION = 3                      # BVH_ABI_VERSION of include/bvh_mi355x.h t
 # bvh_option (bvh_ctx_set_option) and the names this harness accepts for the values
 OPT_HPLOC_SCHEDULER, OPT_LBVH_SCHEDULER, OPT_SORT_TEST_KNOBS, OPT_PLOC_SCHEDULER = 0, 1, 2, 3
 _OPTION_IDS = {"hploc": OPT_HPLOC_SCHEDULER, "lbvh": OPT_LBVH_SCHEDULER, "sort_knobs": OPT_SORT_TEST_KNOBS, "ploc": OPT_PLOC_SCHEDULER}
-_OPTION_VALUES = {"auto": 0, "default": 0, None: 0, "async": 1, "single": 1, "iter": 1, "block": 2, "tiles": 2, "persistent": 2}
+_OPTION_VALUES = {"auto": 0, "default": 0, None: 0, "async": 1, "single": 1, "block": 2, "tiles": 2}     # ("ploc" is reserved: only 0 is accepted)
 
 
 class BuildInput(C.Structure):
@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
         "bvh_build_ex": ([vp, i32, C.POINTER(BuildInput), u32, C.POINTER(Result), C.POINTER(Timings)], i32),
         "bvh_stage_extents_ex": ([vp, C.POINTER(BuildInput), u32, vp, vp], i32),
         "bvh_stage_morton64": ([vp, vp, u32, vp, vp, i32], i32),
+        "bvh_stage_morton_plan": ([vp, vp, i32, C.POINTER(C.c_int32)], i32),
         "bvh_sort_pairs64": ([vp, vp, vp, u32, vp, vp, i32, i32], i32),
         "bvh_stage_extents": ([vp, vp, u32, vp, vp], i32), "bvh_stage_morton": ([vp, vp, u32, vp, vp, vp], i32),
         "bvh_sort_pairs": ([vp, vp, vp, u32, vp, vp, i32, i32], i32),

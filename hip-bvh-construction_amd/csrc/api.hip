@@ -74,6 +74,7 @@ struct bvh_ctx {
     u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
     uint32_t collapse_last_n = 0, collapse_last_levels = 0;   // levels the previous collapse of a tree of this size needed (first batch of launches)
+    uint64_t collapse_last_key = 0;                           // ... of this KIND: {node layout, root index} — an LBVH and a PLOC tree of one size have different level widths
     uint32_t collapse_last_len[COLLAPSE_MAX_BATCH] = {0};     // ... and their task counts (grid sizes of the first batch's launches),
     int collapse_len_batch = 0;                               //     valid for that many levels (0: the previous collapse took several batches)
     int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
@@ -102,27 +103,37 @@ void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_sk
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return -(int)_e; } while (0)
 
-// The per-build read-backs (single-pass LBVH root index, PLOC++ iteration state) are 4-byte copies into pinned host words.  The host learns that one has
-// landed by polling the word itself (the caller stored `sentinel`, a value the device never writes, before enqueuing the copy): hipStreamSynchronize notices
-// the end of the stream ~6 us later than a poll of the word does (tools/probes/sync_latency.hip: 343.6 vs 337.7 us for eight launches + the copy) — 4 % of a
-// 262 144-triangle LBVH build.  The stream is in order, so everything enqueued before the copy is complete when the word changes.  The poll is bounded: after
-// ~4 M reads (some tens of milliseconds: a build that long does not care) it falls back to hipStreamSynchronize, which also surfaces
-// an error of the stream.
+// The per-build read-backs (single-pass LBVH root index, PLOC++ iteration state, the collapse's level counts) are small copies into pinned host words.
+// The host learns that they have landed by polling the words themselves: the caller stores `sentinel` (a value the device never writes) into EVERY word it is
+// going to read before enqueuing the copies, and wait_readback returns once NONE of them holds the sentinel any more — hipStreamSynchronize notices the end of
+// the stream ~6 us later than a poll of the words does (tools/probes/sync_latency.hip: 343.6 vs 337.7 us for eight launches + the copy), 4 % of a
+// 262 144-triangle LBVH build.  Every word is validated on its own (an aligned 4-byte word lands atomically; acquire loads, so nothing read afterwards can be
+// hoisted above the poll): no assumption about the order in which two copies, or the bytes of one copy, become visible to the host (round 3 polled the LAST
+// word only and trusted DMA ordering for the others — ADVICE r03).  The stream is in order, so everything enqueued before the copies is complete when the words
+// have changed.  The poll is bounded: after ~4 M rounds (some tens of milliseconds: a build that long does not care) it falls back to
+// hipStreamSynchronize, which also surfaces an error of the stream.
 #ifndef BVH_POLL_READBACK
 #define BVH_POLL_READBACK 1
 #endif
-static int wait_readback(hipStream_t s, const u32* word, u32 sentinel) {
+static int wait_readback(hipStream_t s, const u32* words, u32 count, u32 sentinel) {
+    auto all_landed = [&]() -> bool {
+        for (u32 i = 0; i < count; ++i) if (__atomic_load_n(words + i, __ATOMIC_ACQUIRE) == sentinel) return false;
+        return true;
+    };
 #if BVH_POLL_READBACK
-    const volatile u32* w = word;
     for (u32 polls = 0; polls < (1u << 22); ++polls) {
-        if (*w != sentinel) return 0;
+        if (all_landed()) return 0;
 #if defined(__x86_64__)
         __builtin_ia32_pause();                      // (be a polite spinner: the runtime's helper threads may share this core)
 #endif
     }
 #endif
     HIP_TRY(hipStreamSynchronize(s));
-    return *(const volatile u32*)word != sentinel ? 0 : BVH_E_INTERNAL;
+    return all_landed() ? 0 : BVH_E_INTERNAL;
+}
+static inline void arm_readback(u32* words, u32 count, u32 sentinel) {
+    for (u32 i = 0; i < count; ++i) __atomic_store_n(words + i, sentinel, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
 }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -159,7 +170,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
     c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);
-    c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH / BVH4 cost, [10..11] u64 checksum, [16..31] camera, [32..47] transform
+    c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH / BVH4 cost, [10..11] u64 checksum, [16..31] camera, [32..47] transform, [48..57] Morton plan read-back
     c->hploc.zero_parent = c->small + 1;
     *total = k.off;
 }
@@ -235,13 +246,13 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
         }
         ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh);
         fresh = false;
-        // two words come back: the iterations done so far, then the cluster count after this batch — the second copy is the one the host polls for
-        // (in-order stream: the first has landed when the second does); counts are < 2^30, the sentinel is not a count
-        u32* const h_iters = c->h_pinned + 1; u32* const h_count = c->h_pinned + 2;
-        *h_count = 0xFFFFFFFFu;
+        // two words come back: the iterations done so far and the cluster count after this batch; the host polls BOTH (wait_readback); counts and
+        // iteration numbers are < 2^30, the sentinel is neither
+        u32* const h_iters = c->h_pinned + 1; u32* const h_count = c->h_pinned + 2;      // (adjacent: one poll covers both)
+        arm_readback(h_iters, 2, 0xFFFFFFFFu);
         HIP_TRY(hipMemcpyAsync(h_iters, sc.state + 2 * PLOC_MAX_ITERS + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_count, sc.state + first + batch, 4, hipMemcpyDeviceToHost, c->stream));
-        { const int wr = wait_readback(c->stream, h_count, 0xFFFFFFFFu); if (wr) return wr; }
+        { const int wr = wait_readback(c->stream, h_iters, 2, 0xFFFFFFFFu); if (wr) return wr; }
         const u32 count = *h_count;
         if (count <= 1) {
             c->ploc_last_n = n; c->ploc_last_iters = *h_iters;
@@ -289,7 +300,8 @@ void bvh_abi_struct_sizes(uint32_t out[3]) { if (out) { out[0] = (uint32_t)sizeo
 int bvh_ctx_set_option(bvh_ctx* c, bvh_option option, int64_t value) {
     if (!c) return BVH_E_INVALID_ARG;
     switch (option) {
-        case BVH_OPT_HPLOC_SCHEDULER: case BVH_OPT_LBVH_SCHEDULER: case BVH_OPT_PLOC_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_HPLOC_SCHEDULER: case BVH_OPT_LBVH_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_PLOC_SCHEDULER: if (value != 0) return BVH_E_INVALID_ARG; break;          // reserved: PLOC++ has one schedule
         case BVH_OPT_SORT_TEST_KNOBS: if (value & ~(int64_t)(8 | 32)) return BVH_E_INVALID_ARG; break;
         default: return BVH_E_INVALID_ARG;
     }
@@ -333,9 +345,10 @@ int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
     if (!c) return BVH_E_INTERNAL;
     c->device = device;
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
-    else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return -(int)e; } c->own_stream = true; }
-    for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { delete c; return -(int)r; } }
-    { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocDefault); if (r != hipSuccess) { delete c; return -(int)r; } }
+    else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { c->stream = nullptr; bvh_ctx_destroy(c); return -(int)e; } c->own_stream = true; }
+    // (a failure from here on goes through bvh_ctx_destroy, which releases whatever exists: stream, events, pinned words)
+    for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { e = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
+    { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocDefault); if (r != hipSuccess) { c->h_pinned = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
     *out = c;
     return 0;
 }
@@ -344,7 +357,7 @@ int bvh_ctx_create(int device, bvh_ctx** out) { return bvh_ctx_create_on_stream(
 void bvh_ctx_destroy(bvh_ctx* c) {
     if (!c) return;
     Bind b(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     if (c->arena) hipFree(c->arena);
     if (c->tris) hipFree(c->tris);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -438,6 +451,17 @@ int bvh_stage_morton64(bvh_ctx* c, const void* d_prim_aabbs, uint32_t n, const v
     return herr(hipGetLastError());
 }
 
+int bvh_stage_morton_plan(bvh_ctx* c, const void* d_scene_extent, int total_bits, int32_t plan_out[10]) {
+    if (!c || !d_scene_extent || !plan_out || total_bits < 3 || total_bits > 60) return BVH_E_INVALID_ARG;
+    Bind b(c->device);
+    int r = ensure_capacity(c, 2); if (r) return r;
+    int* d = reinterpret_cast<int*>(c->small + 48);                      // 10 words of the ctx's small scratch
+    launch_morton_plan(c->stream, d_scene_extent, d, total_bits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(plan_out, d, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    return herr(hipStreamSynchronize(c->stream));
+}
+
 int bvh_stage_extents_ex(bvh_ctx* c, const bvh_build_input* in, uint32_t n, void* d_prim_aabbs, void* d_scene_extent) {
     if (!c || !in || !d_prim_aabbs || !d_scene_extent || n == 0) return BVH_E_INVALID_ARG;
     Bind b(c->device);
@@ -453,7 +477,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     r = begin_emit(c); if (r) return r;
     launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, false, (int)c->options[BVH_OPT_LBVH_SCHEDULER]);
     r = end_emit(c); if (r) return r;
-    if (root_out) { c->h_pinned[0] = 0xFFFFFFFFu; HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, c->stream)); r = wait_readback(c->stream, c->h_pinned, 0xFFFFFFFFu); if (r) return r; *root_out = c->h_pinned[0]; }
+    if (root_out) { arm_readback(c->h_pinned, 1, 0xFFFFFFFFu); HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, c->stream)); r = wait_readback(c->stream, c->h_pinned, 1, 0xFFFFFFFFu); if (r) return r; *root_out = c->h_pinned[0]; }
     return 0;
 }
 
@@ -502,10 +526,11 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
     // E: CalculateSceneExtents (token CalculateCentroidExtentsTime).  The sort's bookkeeping is cleared here so that the
     // Morton kernel can accumulate the digit histograms.
-    // the reference sorts all 32 key bits at its four call sites (src/Hploc.cpp:63-81 ...); the codes have 30 (60) significant bits, and
-    // sorting the full word costs nothing (4 / 8 passes of 8-bit digits either way) while keeping the fused digit histograms of the Morton
-    // kernel — (code >> 24) & 255 for the last pass — and the sort's digit masks equal for ANY key value
-    const int end_bit = key_bits == 64 ? 64 : 32;
+    // the reference sorts all 32 key bits at its four call sites (src/Hploc.cpp:63-81 ...); the codes this build produces have 30 (60) significant bits, so
+    // the build's own sort runs on bits [0, 30) / [0, 60): four (eight) passes either way, but the last one has a 6-bit (4-bit) digit — 64 digit threads,
+    // 6 ballots per key and 64 status words per tile in the look-back instead of 256.  The fused digit histograms of the Morton kernel
+    // — (code >> 24) & 255 for the last pass — hold exactly those digits' counts.  (bvh_sort_pairs keeps full generality for caller-supplied keys.)
+    const int end_bit = key_bits == 64 ? 60 : 30;
     const int passes = sort_passes(0, end_bit);
     r = stage_extents_valid(in); if (r) return r;
     // what a build needs cleared (digit histograms, look-back status rows and tile tickets of `passes` sort passes, the emitters' queue heads) is cleared by
@@ -549,9 +574,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (install.on) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
-        c->h_pinned[0] = 0xFFFFFFFFu;                                                      // (no node has this index: n < 2^30)
+        arm_readback(c->h_pinned, 1, 0xFFFFFFFFu);                                         // (no node has this index: n < 2^30)
         HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, s));      // (pinned: a copy into pageable memory goes through a staging buffer)
-        r = wait_readback(s, c->h_pinned, 0xFFFFFFFFu); if (r) return r;
+        r = wait_readback(s, c->h_pinned, 1, 0xFFFFFFFFu); if (r) return r;
         out->root = c->h_pinned[0];
     }
     out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = scene;
@@ -619,32 +644,33 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
     static_assert(PLOC_STATE_WORDS >= COLLAPSE_STATE_WORDS, "state scratch");
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[5], s));
     collapse_begin(s, taskq, state, in->root, true);
-    // a batch's level counts come back into pinned words (a copy into pageable memory goes through a staging buffer and blocks); the host polls a second,
-    // 4-byte copy of the batch's last count (in-order stream: the words before it have landed) instead of synchronising the stream — see wait_readback
-    u32* const host = c->h_pinned + 16; u32* const flag = c->h_pinned + 3;
+    // a batch's level counts come back into pinned words (a copy into pageable memory goes through a staging buffer and blocks); the host polls every one
+    // of them (counts are < 2^31: the sentinel is not a count) instead of synchronising the stream — see wait_readback
+    u32* const host = c->h_pinned + 16;
     static_assert(COLLAPSE_MAX_BATCH <= PLOC_STATE_WORDS, "pinned read-back words");
     // wide levels ~ half the BVH2 depth: a first batch sized for a balanced tree — or one above what the previous collapse of a tree of this size needed
     // (animation frames, the benchmark loop: a level launched after the end costs ~3 us) —, then batches of 16 until a level creates nothing
     int batch = 10; for (uint32_t m = n; m > 1u; m >>= 1) batch += 1;
-    if (c->collapse_last_n == n && c->collapse_last_levels > 0) batch = (int)c->collapse_last_levels + 1;
+    const uint64_t hint_key = ((uint64_t)in->layout << 32) | (uint64_t)in->root;
+    const bool hinted = c->collapse_last_n == n && c->collapse_last_key == hint_key;
+    if (hinted && c->collapse_last_levels > 0) batch = (int)c->collapse_last_levels + 1;
     if (batch > COLLAPSE_MAX_BATCH) batch = COLLAPSE_MAX_BATCH;
     u32 base_begin = 0, base_len = 1, levels = 0;                      // the root task
     for (long long total = 0; total < (1ll << 31); total += batch, batch = 16) {
-        const bool known = total == 0 && c->collapse_last_n == n && c->collapse_len_batch > 0 && batch <= c->collapse_len_batch + 1;
+        const bool known = total == 0 && hinted && c->collapse_len_batch > 0 && batch <= c->collapse_len_batch + 1;
         collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, base_begin, base_len, batch, n, (int)in->layout,
                          known ? c->collapse_last_len : nullptr);
         HIP_TRY(hipGetLastError());
-        *flag = 0xFFFFFFFFu;
+        arm_readback(host, (u32)batch, 0xFFFFFFFFu);
         HIP_TRY(hipMemcpyAsync(host, state, (size_t)batch * sizeof(u32), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(flag, state + batch - 1, sizeof(u32), hipMemcpyDeviceToHost, s));
-        r = wait_readback(s, flag, 0xFFFFFFFFu); if (r) return r;
+        r = wait_readback(s, host, (u32)batch, 0xFFFFFFFFu); if (r) return r;
         u32 len = base_len, allocated = base_begin + base_len;       // ids handed out so far
         u32 lens[COLLAPSE_MAX_BATCH + 1]; lens[0] = base_len;
         for (int l = 0; l < batch; ++l) { if (len) ++levels; len = host[l]; allocated += len; lens[l + 1] = len; }
         if (host[batch - 1] == 0u) {                   // the batch's last level allocated nothing: every later one would have no work
             if (n_wide_out) *n_wide_out = allocated;
             // (remembered only when the whole collapse was one batch: then level l of the next first batch is level l of this one)
-            c->collapse_last_n = n; c->collapse_last_levels = levels;
+            c->collapse_last_n = n; c->collapse_last_levels = levels; c->collapse_last_key = hint_key;
             c->collapse_len_batch = 0;
             if (total == 0) { c->collapse_len_batch = batch; for (int l = 0; l < COLLAPSE_MAX_BATCH; ++l) c->collapse_last_len[l] = l < batch ? lens[l] : 0u; }
             if (c->profiling) {   // token CollapseBvhTime (src/TwoPassLbvh.cpp:182), including this implementation's level read-backs

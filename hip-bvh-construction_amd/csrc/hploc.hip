@@ -804,6 +804,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)my_gap[i];
     __syncthreads();
 #endif
+#if HPB_DEPS
+    static_assert(!HPB_LEAN, "HPB_DEPS needs the key window during the level loop");
+#endif
     if (dbg == 2) return;
 #ifdef BVH_ABLATION       // measurement build: merge tasks run by the tile kernel (word 2 of sub-queue 0's padded head; read through BVH_OPT_DEBUG_TASKS_LOCAL)
     if (tid == 0) { u32 t = 0; for (int lv = 0; lv < NLEV; ++lv) t += s_cnt[lv]; atomicAdd(q_count + 2, t); }
@@ -815,6 +818,25 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #elif HPB_PRIO == 3
     __builtin_amdgcn_s_setprio(0);
 #endif
+#ifndef HPB_ROT
+#define HPB_ROT 0        // 1: the wave that takes a level's first task pair rotates with the tile index.  A workgroup's wave w runs on SIMD w of its CU (four waves, dealt
+#endif                   //    round-robin), and a thin level (<= 2 tasks: the top of every tile's hierarchy) only occupies the first wave: without the rotation the thin levels of
+                         //    all seven resident tiles queue on ONE SIMD while the other three idle.  Measured (round 4): the premise is wrong — tools/probes/simd_map.hip
+                         //    shows the hardware starts every workgroup's round-robin on the next SIMD (wave 0 lands on each SIMD a quarter of the time) — and the
+                         //    switch changes nothing (0.6500 / 0.6515 vs 0.6511 / 0.6495 ms).  Off.
+#if HPB_ROT
+    const u32 wrot = ((u32)wave + blockIdx.x) & (u32)(NW - 1);
+#else
+    const u32 wrot = (u32)wave;
+#endif
+#ifndef HPB_DEPS_SLEEP
+#define HPB_DEPS_SLEEP 2 // (x 64 cycles between two polls of a waiting wave)
+#endif
+#ifndef HPB_DEPS
+#define HPB_DEPS 0       // 1: no barrier between the levels of a tile's hierarchy — a task starts as soon as its own big children have finished.  Every finished task adds 1
+#endif                   //    to bits 30..31 of its parent's m_range word (if the parent is a local task); a task waits (s_sleep) until its word shows as many arrivals as it
+                         //    has big children.  Waves walk their static share of the level-sorted task list in order, so whatever a task waits for sits EARLIER in some
+                         //    wave's sequence: no cycle.  A wave's LDS operations execute in order: the survivors a task wrote are in LDS before its arrival count is.
     for (int lv = 0; lv < NLEV; ++lv) {
         const u32 c = s_cnt[lv];
         if (!c) continue;                            // block-uniform
@@ -822,11 +844,21 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #if HPB_PRIO == 1
         if (c <= 2u) __builtin_amdgcn_s_setprio(3); else if (c <= 4u) __builtin_amdgcn_s_setprio(2); else if (c <= 8u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-        for (u32 tw = (u32)wave * 2u; tw < c; tw += (u32)NW * 2u) {
+        for (u32 tw = wrot * 2u; tw < c; tw += (u32)NW * 2u) {
             const u32 t = tw + (u32)half;
             const bool have = t < c;
             u32 P = 0, L = 0, R = 0;
-            if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0xFFFFu; R = rg >> 16; }
+            if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0xFFFFu; R = (rg >> 16) & 0x3FFFu; }
+#if HPB_DEPS
+            {   const u32 need = have ? ((P - L + 1u > HP_HALF ? 1u : 0u) + (R - P > HP_HALF ? 1u : 0u)) : 0u;
+                while (true) {
+                    const u32 got = have ? (__hip_atomic_load(&m_range[P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 30) : 0u;
+                    if (!__ballot(have && got != need)) break;
+                __builtin_amdgcn_s_sleep(HPB_DEPS_SLEEP);
+                }
+                compiler_fence();                    // the list reads below stay behind the poll
+            }
+#endif
             // loadIndices (:192-206) from the LDS work lists: the first <= 16 valid entries of each child range, left-packed on the fly; the rounds
             // run on the list in place and leave the survivors at the range's first positions (storeIndices :208-218)
             const bool is_left = slot < 16;
@@ -849,9 +881,27 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
             ploc_rounds_lds<false, HPB_IL != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
+#if HPB_DEPS
+            if (have && slot == 0) {                 // tell the parent, if it is a task of this tile
+                const u32 gL = g0 + L, gR = g0 + R;
+                if (!(gL == 0u && gR == ni)) {
+                    const u32 q = parent_gap(gL, gR, ni, [&](u32 a, u32 b2) {   // both pairs lie inside the key window (margin KM)
+                        return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b2), b2, wkey((int)b2 + 1), b2 + 1u); });
+                    if (q >= g0 && q - g0 < (u32)T) {
+                        const u32 pr = __hip_atomic_load(&m_range[q - g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (pr != M_EXT && pr != 0u) { compiler_fence(); atomicAdd(&m_range[q - g0], 1u << 30); }
+                    }
+                }
+            }
+#endif
         }
+#if !HPB_DEPS
         __syncthreads();
+#endif
     }
+#if HPB_DEPS
+    __syncthreads();
+#endif
 #if HPB_PRIO == 1 || HPB_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -894,7 +944,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 }
             } else if (m_range[k] != 0u) {           // local big node
                 const u32 rg = m_range[k];
-                const u32 L = g0 + (rg & 0xFFFFu), R = g0 + (rg >> 16);
+                const u32 L = g0 + (rg & 0xFFFFu), R = g0 + ((rg >> 16) & 0x3FFFu);         // (bits 30..31: HPB_DEPS arrival count)
                 const u32 q = parent_gap(L, R, ni, [&](u32 a, u32 b) {   // both pairs lie inside the key window
                     return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b), b, wkey((int)b + 1), b + 1u); });
                 if (q < g0 || m_range[q - g0] == M_EXT) s_task[atomicAdd(&s_npub, 1u)] = (unsigned short)(k | (q == R ? 0u : 0x8000u));
@@ -914,7 +964,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             if (on) {
                 const u32 tk = s_task[j];
                 const u32 rg = m_range[tk & 0x7FFFu];
-                const u32 Lr = rg & 0xFFFFu; L = g0 + Lr; R = g0 + (rg >> 16); right = (tk & 0x8000u) != 0u;
+                const u32 Lr = rg & 0xFFFFu; L = g0 + Lr; R = g0 + ((rg >> 16) & 0x3FFFu); right = (tk & 0x8000u) != 0u;
                 const u32 sp = Lr + (u32)sl;
                 TileList::Tag tg; Box b;
                 tl.load(sp, tg, b);
@@ -949,13 +999,15 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 // drain, no atomic, and only the sibling's records to load.  Otherwise the usual protocol runs unchanged.  (Whenever a node's continuation
 // passes to another wave it is through the usual protocol, whose drain also covers the node stores made since.)
 #ifdef ABL_EXT_TRACE     // measurement build: the tasks of more than n / 4096 leaves leave {start, end (100 MHz clock), range, hand-over taken} in the unused tail of the queue buffer
-__device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap, u64 t0, u32 L, u32 R, u32 ni, u32 kind, u32 nrounds) {
+__device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap, u64 t0, u32 L, u32 R, u32 ni, u32 kind, u32 nrounds, u64 t_loaded = 0, u64 t_rounds = 0) {
     if ((R - L + 1u) <= (ni + 1u) / 4096u) return;
 #ifdef EXT_TRACE_NOP
     return;
 #endif
     const u32 at = atomicAdd(trace_count, 1u);
-    if (at < cap) { u64* e = trace + (size_t)at * 4u; e[0] = t0; e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = (u64)L | ((u64)R << 32); e[3] = (u64)kind | ((u64)nrounds << 8); }
+    // e[3]: kind | rounds << 8 | (ticks from the pass's start to "work list loaded") << 16 | (... to "rounds done") << 32 (100 MHz ticks, 16 bits each)
+    if (at < cap) { u64* e = trace + (size_t)at * 4u; e[0] = t0; e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = (u64)L | ((u64)R << 32);
+                    e[3] = (u64)kind | ((u64)nrounds << 8) | (((t_loaded - t0) & 0xFFFFull) << 16) | (((t_rounds - t0) & 0xFFFFull) << 32); }
 }
 #define EXT_TRACE_ARGS , u64* trace = nullptr, u32* trace_count = nullptr, u32 trace_cap = 0u
 #define EXT_TRACE_PASS , trace, trace_count, trace_cap
@@ -1020,7 +1072,11 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, [&]() { ++nrounds; });
     const u64 t2 = __builtin_amdgcn_s_memtime();
 #elif defined(ABL_EXT_TRACE) && !defined(EXT_TRACE_NOHOOK)
+    asm volatile("" : "+v"(w.b.lx), "+v"(w.id));                            // (the list is in registers before the stamp)
+    const u64 tr1 = __builtin_amdgcn_s_memrealtime();
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, [&]() { ++tr_rounds; });
+    asm volatile("" : "+v"(w.b.lx), "+v"(w.id));
+    const u64 tr2 = __builtin_amdgcn_s_memrealtime();
 #elif HPX_LDS_LIST
     {   // the rounds run on the half's list in LDS (ploc_rounds_lds: the partner is read, survivors are written to their rank — no crossbar operations,
         // ~50 fewer VALU instructions per round); the list is filled from the left-packed registers and the survivors are read back into them
@@ -1064,7 +1120,11 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     }
     cw.id = w.id; cw.rep = w.rep; cw.b = w.b;
 #ifdef ABL_EXT_TRACE
+#if !defined(EXT_TRACE_NOHOOK)
+    if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds, tr1, tr2);
+#else
     if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds);
+#endif
 #endif
 #ifdef ABL_EXT_TIMING
     {   const u64 t3 = __builtin_amdgcn_s_memtime();

@@ -42,6 +42,9 @@ void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d
 void launch_morton64(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint64_t* d_keys, int total_bits,
                      uint32_t* d_hist /*may be null*/, int passes, float* d_reset_next = nullptr);
 
+// the per-scene bit plan the Morton kernels derive from a scene extent, evaluated on the device: int[10] = {axis[3], bits[3], pre[2], pre_sum, swap}
+void launch_morton_plan(hipStream_t s, const void* d_scene, int* d_out, int total_bits);
+
 // ---- stage S (sort.hip): one-sweep LSD radix sort, SORT_BITS-bit digits
 constexpr int SORT_BITS = 8;
 constexpr int SORT_RADIX = 1 << SORT_BITS;

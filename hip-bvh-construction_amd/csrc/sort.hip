@@ -9,11 +9,16 @@
 //  * 8-bit digits; every pass reads each pair once and writes it once (16 B per pair per pass) — the digit histograms of
 //    ALL passes are produced up front (fused into the Morton kernel, or by k_hist for the stand-alone entry point), so no
 //    pass re-reads keys to count; every tile scans the 256 raw counts of its pass itself (no scan launch).
-//  * one workgroup (4 wave64) sorts a tile of 4096 pairs: per-wave ranking by ballot "match-any" (8 ballots per key, no
-//    LDS atomics, stable by construction), per-wave digit counters in LDS, a cross-wave scan, then the tile's digit totals
-//    are chained to earlier tiles by decoupled look-back on 32-bit status words {flag:2, count:30}.  Status words are
-//    relaxed agent-scope atomics: the value is its own flag, so no fence is needed across XCDs.
-//  * tile ids come from an atomic ticket, so a tile only ever waits on tiles that are already running.
+//  * one workgroup sorts a tile: 512 threads x 13 pairs = 6656 pairs from SORT_WIDE_MIN_N keys on (two workgroups per CU, 61 KB of LDS), 1024 threads x 3
+//    pairs = 3072 below (a pass is then one generation of tiles: what counts is a tile's latency).  Per-wave ranking by ballot "match-any" (one ballot
+//    per digit bit and key, no LDS atomics, stable by construction), per-wave digit counters in LDS, a cross-wave scan, then the tile's digit totals are
+//    chained to earlier tiles by decoupled look-back on 32-bit status words {flag:2, count:30}.  Status words are relaxed agent-scope atomics: the value
+//    is its own flag, so no fence is needed across XCDs.
+//  * tile id = workgroup id (no ticket: a returning atomic on one word per tile cost 10 us of every pass).  Progress under ANY dispatch order comes from
+//    helping: a thread that has polled an unpublished predecessor SORT_HELP_AFTER times counts that tile's keys for its digit itself and publishes the
+//    total on its behalf (idempotent).
+//  * the digit width is a template parameter (round 4): the build sorts its 30-bit Morton codes as 8 / 8 / 8 / 6 bits, and the 6-bit last pass runs with 64
+//    digit threads, 6 ballots per key and 64 status words per tile instead of 256 (192 of them were structurally zero).
 //  * pairs are staged through LDS in their tile-sorted order so that global writes are runs of consecutive addresses.
 #include <cstdlib>
 #include "common.hpp"
@@ -21,7 +26,7 @@
 
 namespace bvh {
 
-static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit (k_onesweep: the first SORT_RADIX threads of the workgroup)");
+static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit (k_onesweep: the first 2^BITS threads of the workgroup)");
 constexpr u32 ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 
 // interleaved {key, value} records of the intermediate passes: 8 bytes for u32 keys, 16 bytes {key, value, pad} for u64 keys
@@ -100,24 +105,27 @@ template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };  
 #ifndef SORT_EXCHANGE_FIRST
 #define SORT_EXCHANGE_FIRST 1
 #endif
-template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK>
+// BITS: digit width of this instantiation's pass (6..8; a pass whose digit is narrower than BITS passes a smaller digit_mask).  Status rows keep their
+// SORT_RADIX-word stride; a pass only touches the first 2^BITS words of a row.
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK, int BITS = SORT_BITS>
 __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
                                                          int shift, u32 digit_mask, const u32* __restrict__ ghist,
                                                          u32* status, u32* tile_counter, int dbg) {
-    constexpr int NW = NT / WAVE, NDW = SORT_RADIX / WAVE;        // waves; waves that own digits (threads 0..255: one digit each)
+    constexpr int RADIX = 1 << BITS;
+    constexpr int NW = NT / WAVE, NDW = RADIX / WAVE;             // waves; waves that own digits (threads 0 .. RADIX-1: one digit each)
     constexpr int TILE = NT * IPT;                   // keys per workgroup
-    static_assert(NT % SORT_RADIX == 0, "digit threads are whole waves");
-    __shared__ u32 s_whist[NW][SORT_RADIX];
-    __shared__ u32 s_binoff[SORT_RADIX];
-    __shared__ u32 s_gbase[SORT_RADIX];
+    static_assert(BITS >= 6 && BITS <= SORT_BITS && NT % RADIX == 0, "digit threads are whole waves");
+    __shared__ u32 s_whist[NW][RADIX];
+    __shared__ u32 s_binoff[RADIX];
+    __shared__ u32 s_gbase[RADIX];
     using Rec = PairRec<K>;
     __shared__ K s_keys[TILE];
     __shared__ u32 s_vals[TILE];
     __shared__ u64 s_wsum[NW];
     __shared__ u32 s_tile;
 #if SORT_EARLY_PUBLISH
-    __shared__ u32 s_cnt[SORT_RADIX];
+    __shared__ u32 s_cnt[RADIX];
 #endif
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #else
     if (tid == 0) s_tile = (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 #endif
-    const bool dig = tid < SORT_RADIX;               // this thread speaks for digit `tid`
+    const bool dig = tid < RADIX;                    // this thread speaks for digit `tid`
     if (dig) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         // lanes whose digit differs from mine in bit b: ballot(bit b) xor (my bit b, sign-extended); the group is what is left
         u32 diff_lo = 0u, diff_hi = 0u;
 #pragma unroll
-        for (int b = 0; b < SORT_BITS; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const int mine = __builtin_amdgcn_sbfe((int)d, b, 1);           // 0 or -1
             const u64 bal = __ballot(mine != 0);
             diff_lo |= (u32)bal ^ (u32)mine; diff_hi |= (u32)(bal >> 32) ^ (u32)mine;
@@ -435,12 +443,14 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         u32* tc = sc.counters + p;
         KernelScope ks(s, "k_onesweep");
         const dim3 g(tiles), bn(SORT_NARROW_NT), bw(SortWide<K>::NT);
-#define SWEEP(IOTA, INA, OUTA) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
-                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT>), g, bn, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
+#define SWEEP_B(IOTA, INA, OUTA, BB) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT, BB>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
+                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT, BB>), g, bn, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
+#define SWEEP(IOTA, INA, OUTA) SWEEP_B(IOTA, INA, OUTA, SORT_BITS)
         if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }
-        else if (last)          SWEEP(false, true, false);
-        else                    SWEEP(false, true, true);
+        else if (last)          { if (w <= 6) SWEEP_B(false, true, false, 6); else if (w == 7) SWEEP_B(false, true, false, 7); else SWEEP(false, true, false); }   // a narrow top digit:
+        else                    SWEEP(false, true, true);                                                                   // fewer digit threads, ballots and status words
+#undef SWEEP_B
 #undef SWEEP
 #ifdef BVH_ABLATION
         if (dbg & 16) hipLaunchKernelGGL(k_lb_report, dim3(1), dim3(1), 0, s, tc, tiles, p);

@@ -395,6 +395,18 @@ void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d
     hipLaunchKernelGGL(k_extents_indexed, dim3(ex_grid(n)), dim3(EX_BLOCK), 0, s, (const float*)d_vertices, (const u32*)d_indices, n_vertices, (bvh_aabb*)d_boxes, (float*)d_scene, n, pa);
 }
 
+// the per-scene plan of the Morton kernels, as the device evaluates it (bvh_stage_morton_plan): {axis[3], bits[3], pre[2], pre_sum, swap}
+__global__ void k_morton_plan(const float* __restrict__ scene, int* __restrict__ out, u32 total_bits) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    MortonPlan m; float lo[3], ext[3];
+    make_plan(scene, m, lo, ext, total_bits);
+    for (int i = 0; i < 3; ++i) { out[i] = m.axis[i]; out[3 + i] = m.bits[i]; }
+    out[6] = m.pre[0]; out[7] = m.pre[1]; out[8] = m.pre_sum; out[9] = m.swap;
+}
+void launch_morton_plan(hipStream_t s, const void* d_scene, int* d_out, int total_bits) {
+    hipLaunchKernelGGL(k_morton_plan, dim3(1), dim3(64), 0, s, (const float*)d_scene, d_out, (u32)total_bits);
+}
+
 void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
                    u32* d_hist, int hist_bits, int passes, float* d_reset_next) {
     const dim3 g(em_grid(n)), b(EM_BLOCK);

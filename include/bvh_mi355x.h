@@ -69,7 +69,10 @@ typedef struct {
     uint32_t sampled;                  /* 1: the ms_* fields of this build were recorded; 0: they are zero — profiling is off, or
                                           bvh_ctx_set_kernel_sampling(ctx, k) made this one of the k-1 un-instrumented builds (hosts that
                                           average ms_* over builds must skip those) */
-    uint64_t bytes_algorithmic;        /* DESIGN.md "algorithmic bytes" for this build (n x per-prim figure) */
+    uint64_t bytes_algorithmic;        /* n x the NOMINAL per-primitive figure of SURVEY.md 8(d) (two-pass 384, single-pass 420, PLOC++ 438, HPLOC 386): mesh
+                                          independent.  The exact figure of a PLOC-family build depends on the mesh's cluster loads / stores, which only the
+                                          oracle counts (profiles/algorithmic_bytes.json, e.g. 387.98 for the 10 M uniform HPLOC build); bench.py prices its
+                                          roofline with the exact figure when that file covers the workload and says which one it used */
 } bvh_timings;
 /* level 0: no events (bvh_build fully asynchronous where it can be); 1: one event per stage (the reference's Timer tokens);
  * 2: additionally one event pair around every kernel launch, summed by bvh_ctx_kernel_times. */
@@ -138,6 +141,11 @@ int  bvh_build_ex(bvh_ctx* ctx, bvh_algo algo, const bvh_build_input* in, uint32
 int  bvh_stage_extents_ex(bvh_ctx* ctx, const bvh_build_input* in, uint32_t n, void* d_prim_aabbs, void* d_scene_extent);
 /* stage M with a total_bits budget (<= 60) into u64 keys; total_bits = 30 reproduces bvh_stage_morton's codes */
 int  bvh_stage_morton64(bvh_ctx* ctx, const void* d_prim_aabbs, uint32_t n, const void* d_scene_extent, uint64_t* d_keys, int total_bits);
+/* The per-scene bit plan of stage M exactly as the device evaluates it (src/CommonBlocksKernel.h:162-275: axis order by extent, pre-bits from (int)log2f of the
+ * extent ratios, the bit budget): plan_out = {axis[3], bits[3], pre[2], pre_sum, swap}.  total_bits 30 = bvh_stage_morton, <= 60 = bvh_stage_morton64.  A host
+ * that must reproduce the codes bit for bit (an oracle, a CPU fallback of its own) takes the plan from here instead of evaluating log2f with another math
+ * library: OCML and a host libm may truncate differently when a ratio sits within an ulp of a power of two.  Blocking (one small read-back). */
+int  bvh_stage_morton_plan(bvh_ctx* ctx, const void* d_scene_extent, int total_bits, int32_t plan_out[10]);
 /* stage S on u64 keys, key bits [start_bit, end_bit) with end_bit <= 64 */
 int  bvh_sort_pairs64(bvh_ctx* ctx, const uint64_t* d_keys_in, const uint32_t* d_vals_in, uint32_t n,
                       uint64_t* d_keys_out, uint32_t* d_vals_out, int start_bit, int end_bit);

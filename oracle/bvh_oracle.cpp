@@ -304,6 +304,23 @@ void orc_morton_codes(const void* boxes, u32 stride_bytes, u32 box_offset_bytes,
     }
 }
 
+// the same with the per-scene plan GIVEN (int[10] as orc_morton_plan writes it) instead of derived from the extent: tests/test_gpu_round4.py feeds the plan the
+// DEVICE evaluated (bvh_stage_morton_plan) to show that a key difference at an extent ratio within an ulp of a power of two is the log2f truncation and nothing else
+void orc_morton_codes_plan(const void* boxes, u32 stride_bytes, u32 box_offset_bytes, u32 n, const void* scene, const int* plan, u32* keys_out) {
+    const Box* s = (const Box*)scene;
+    const F3 e = { s->hi.x - s->lo.x, s->hi.y - s->lo.y, s->hi.z - s->lo.z };
+    MortonPlan m;
+    for (int i = 0; i < 3; ++i) { m.axis[i] = plan[i]; m.bits[i] = plan[3 + i]; }
+    m.pre[0] = plan[6]; m.pre[1] = plan[7]; m.pre_sum = plan[8]; m.swap = plan[9];
+    const char* base = (const char*)boxes + box_offset_bytes;
+    for (u32 i = 0; i < n; ++i) {
+        Box b; std::memcpy(&b, base + (size_t)i * stride_bytes, sizeof(Box));
+        const F3 c = { (b.hi.x + b.lo.x) * 0.5f, (b.hi.y + b.lo.y) * 0.5f, (b.hi.z + b.lo.z) * 0.5f };
+        const float p[3] = { (c.x - s->lo.x) / e.x, (c.y - s->lo.y) / e.y, (c.z - s->lo.z) / e.z };
+        keys_out[i] = morton_encode(m, p);
+    }
+}
+
 // u64 keys with a total_bits budget (30 reproduces orc_morton_codes)
 void orc_morton_codes64(const void* boxes, u32 stride_bytes, u32 box_offset_bytes, u32 n, const void* scene, int total_bits, u64* keys_out) {
     const Box* s = (const Box*)scene;

@@ -105,6 +105,15 @@ def morton_codes(boxes: np.ndarray, scene: np.ndarray):
     return keys, vals
 
 
+def morton_codes_with_plan(boxes: np.ndarray, scene: np.ndarray, plan) -> np.ndarray:
+    """orc_morton_codes_plan: the oracle's encoder driven by a GIVEN per-scene plan (list of 10 ints: axis[3], bits[3], pre[2], pre_sum, swap)"""
+    n = boxes.shape[0]
+    keys = np.empty(n, dtype=np.uint32); pl = np.asarray(plan, dtype=np.int32)
+    L = lib(); L.orc_morton_codes_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_morton_codes_plan(boxes.ctypes.data, boxes.dtype.itemsize, 0, n, scene.ctypes.data, pl.ctypes.data, keys.ctypes.data)
+    return keys
+
+
 def morton_codes64(boxes: np.ndarray, scene: np.ndarray, total_bits: int = 60) -> np.ndarray:
     """u64 extended Morton codes with a total_bits budget (30 reproduces morton_codes)"""
     n = boxes.shape[0]
@@ -304,6 +313,29 @@ def ref_emu_ploc(boxes, svals):
     if rc != 0:
         raise RuntimeError(f"ref_emu_ploc failed: {rc}")
     return nodes, leaves, int(it.value)
+
+
+REF_HPLOC_EMU = os.path.join(_HERE, "_ref", "libref_hploc_emu.so")
+_emu_h = None
+
+
+def ref_emu_hploc(boxes, skeys, svals, cover_all=False):
+    """SetupClusters + HPloc of the reference (src/HplocKernel.h, host src/Hploc.cpp:83-121) executed on the CPU by the same SIMT emulator that runs the
+    Ploc / collapse kernels.  The same header runs unmodified on the MI355X (ref_hploc): comparing the two checks the EMULATOR against silicon.
+    -> (nodes, leaves, merged) or None when the library is not built (needs /root/reference)."""
+    global _emu_h
+    if not os.path.exists(REF_HPLOC_EMU):
+        return None
+    if _emu_h is None:
+        _emu_h = C.CDLL(REF_HPLOC_EMU)
+        _emu_h.ref_emu_hploc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+    n = boxes.shape[0]
+    boxes = np.ascontiguousarray(boxes); skeys = np.ascontiguousarray(skeys, dtype=np.uint32); svals = np.ascontiguousarray(svals, dtype=np.uint32)
+    nodes = np.zeros(max(n - 1, 1), dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); merged = C.c_uint32()
+    rc = _emu_h.ref_emu_hploc(boxes.ctypes.data, skeys.ctypes.data, svals.ctypes.data, n, nodes.ctypes.data, leaves.ctypes.data, C.byref(merged), int(cover_all))
+    if rc != 0:
+        raise RuntimeError(f"ref_emu_hploc failed: {rc}")
+    return nodes[: n - 1], leaves, int(merged.value)
 
 
 REF_LBVH_EMU = os.path.join(_HERE, "_ref", "libref_lbvh_emu.so")

@@ -62,7 +62,7 @@ def require_ref(present, what: str) -> None:
 
 @pytest.fixture
 def sched_opts(ctx):
-    """sched_opts(hploc="block", lbvh="block", sort_knobs=8, ploc="persistent") sets bvh_ctx options on the session ctx for one test; all are reset afterwards.
+    """sched_opts(hploc="block", lbvh="block", sort_knobs=8) sets bvh_ctx options on the session ctx for one test; all are reset afterwards.
     (The library reads no environment variables: schedulers are chosen by size unless the host overrides them per context.)"""
     def setter(**kw):
         for k, v in kw.items():

@@ -54,7 +54,9 @@ def test_stage_extents_and_morton(pkg, orc, ctx, cases, name):
     assert np.array_equal(d_vals.download(np.uint32, n), vals)
 
 
-@pytest.mark.parametrize("n,bits", [(1, 32), (2, 32), (255, 32), (4096, 32), (4097, 32), (100_003, 32), (1_000_000, 32), (999_999, 32), (2_500_001, 21), (100_003, 30), (100_003, 13), (5000, 0)])
+@pytest.mark.parametrize("n,bits", [(1, 32), (2, 32), (255, 32), (4096, 32), (4097, 32), (100_003, 32), (1_000_000, 32), (999_999, 32), (2_500_001, 21), (100_003, 30), (100_003, 13), (5000, 0),
+                                    # round 4: narrow top digits run with their own digit width (6 / 7 bits: 64 / 128 digit threads) in both tile shapes
+                                    (1_500_000, 30), (1_500_000, 31), (100_003, 31), (1_500_003, 26), (300_000, 17)])
 def test_sort_pairs(pkg, orc, ctx, n, bits):
     rng = np.random.default_rng(n * 31 + bits)
     keys = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)

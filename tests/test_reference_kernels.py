@@ -81,3 +81,35 @@ def test_reference_hploc_kernel(pkg, orc, drv, ctx, kind, n, seed, nofma):
         assert orc.topology_hash(nodes, leaves, 0, n, 1) == orc.topology_hash(onodes, oleaves, 0, n, 1), "CPU oracle topology != reference HPloc"
         g = got.download()
         assert orc.topology_hash(g["nodes"], g["leaves"], 0, n, 1) == orc.topology_hash(nodes, leaves, 0, n, 1)
+
+
+EMU_MESHES = [("cornell", 32, 0), ("cornell", 82, 0), ("cornell", 382, 0), ("uniform", 1000, 21), ("uniform", 33, 23), ("uniform", 65, 24), ("uniform", 4097, 5),
+              ("dups", 3000, 9), ("flat", 2000, 8), ("sponza", 40_000, 3), ("bunny", 30_000, 2), ("uniform", 50_000, 22)]
+
+
+@pytest.mark.parametrize("kind,n,seed", EMU_MESHES)
+def test_emulator_matches_hardware_on_hploc(pkg, orc, drv, kind, n, seed):
+    """The instrument check behind the PLOC++ / collapse pins.  The reference's `Ploc` kernel hard-codes wave32 and cannot run on
+    gfx950, so its only executable form is the CPU SIMT emulator (tools/oracle/ref_emulator.cpp) — whose __ballot / __shfl / __syncthreads / LDS atomicMin(u64)
+    / global atomic semantics are this repository's own.  HplocKernel.h speaks the same vocabulary AND runs unmodified on the MI355X: the SAME header under
+    the emulator must build the same tree as on the hardware (contraction off on both sides so that area ties break alike) — same number of merges, same
+    leaves, same canonical topology, same SAH."""
+    require_ref(os.path.exists(orc.REF_HPLOC_EMU), "oracle/_ref/libref_hploc_emu.so (the reference's HPloc kernel under the CPU emulator)")
+    if kind == "cornell":
+        tris = pkg.meshgen.load_tri(os.path.join(os.path.dirname(__file__), "golden", f"cornell{n}.tri"))
+    elif kind == "dups":
+        tris = pkg.meshgen.uniform(n, seed); tris[::3] = tris[1]          # heavy duplicate keys: ties everywhere
+    elif kind == "flat":
+        tris = pkg.meshgen.uniform(n, seed); tris["v1"][:, 2] = 0.25; tris["v2"][:, 2] = 0.25; tris["v3"][:, 2] = 0.25   # zero extent in z
+    else:
+        tris = _mesh(pkg, kind, n, seed)
+    n = len(tris)
+    fe = orc.front_end(tris)
+    cover_all = (n - 1) % 32 == 0          # both sides cover every leaf where the reference's launch would miss the last one
+    e_nodes, e_leaves, e_merged = orc.ref_emu_hploc(fe["boxes"], fe["skeys"], fe["svals"], cover_all=cover_all)
+    h_nodes, h_leaves, h_merged = orc.ref_hploc(fe["boxes"], fe["skeys"], fe["svals"], nofma=True, cover_all=cover_all)
+    assert e_merged == h_merged == n - 1
+    assert e_leaves.tobytes() == h_leaves.tobytes()
+    assert orc.validate_bvh2(e_nodes, e_leaves, 0, n, 1) == 0 and orc.validate_bvh2(h_nodes, h_leaves, 0, n, 1) == 0
+    assert orc.topology_hash(e_nodes, e_leaves, 0, n, 1) == orc.topology_hash(h_nodes, h_leaves, 0, n, 1), "emulated HPloc != HPloc on the MI355X"
+    assert orc.sah_bvh2(e_nodes, e_leaves, 0, n, 1)[0] == orc.sah_bvh2(h_nodes, h_leaves, 0, n, 1)[0]

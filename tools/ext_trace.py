@@ -26,7 +26,9 @@ t_start = int(tr[tr[:, 2] == 0][0, 0])
 ev = tr[tr[:, 2] != 0]
 t0 = (ev[:, 0].astype(np.int64) - t_start) / 100.0; t1 = (ev[:, 1].astype(np.int64) - t_start) / 100.0      # us (100 MHz clock)
 L = (ev[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64); R = (ev[:, 2] >> np.uint64(32)).astype(np.int64)
-kind = (ev[:, 3] & np.uint64(0xFF)).astype(int); rounds = (ev[:, 3] >> np.uint64(8)).astype(int)
+kind = (ev[:, 3] & np.uint64(0xFF)).astype(int); rounds = ((ev[:, 3] >> np.uint64(8)) & np.uint64(0xFF)).astype(int)
+d_load = ((ev[:, 3] >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64) / 100.0       # us from the pass's start until the work list is in registers
+d_rnd = ((ev[:, 3] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64) / 100.0        # ... until the rounds are done
 size = R - L + 1
 print(f"n={n}: {len(ev)} traced tasks; first start {t0.min():.1f} us, last end {t1.max():.1f} us")
 names = {1: "fast(late)", 2: "slow-continue", 3: "stop", 4: "fast(early)"}
@@ -50,5 +52,9 @@ while True:
     kids = [k for k in mx if (L[k] == L[cur] or R[k] == R[cur])]
     if not kids: break
     cur = max(kids, key=lambda k: t1[k])
-print("critical chain from the root downwards: size, start, end, rounds, hand-over")
-for c in chain: print(f"  {size[c]:9d}  {t0[c]:7.1f} -> {t1[c]:7.1f}  ({t1[c]-t0[c]:5.2f} us, {rounds[c]} rounds)  {names.get(kind[c], kind[c])}")
+print("critical chain, bottom-up: size, start, end, rounds, hand-over kind; then the level's phases in us")
+prev_end = None
+for c in reversed(chain):
+    gap = (t0[c] - prev_end) if prev_end is not None else 0.0
+    print(f"  {size[c]:9d}  {t0[c]:7.1f} -> {t1[c]:7.1f}  ({t1[c]-t0[c]:5.2f} us, {rounds[c]} rounds)  {names.get(kind[c], kind[c])}   gap before {gap:5.2f}  list load {d_load[c]:5.2f}  rounds {d_rnd[c]-d_load[c]:5.2f}  hand-over {t1[c]-t0[c]-d_rnd[c]:5.2f}")
+    prev_end = t1[c]

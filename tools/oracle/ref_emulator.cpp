@@ -1,10 +1,17 @@
 // ref_emulator.cpp — runs the REFERENCE's own device code on the CPU under a small SIMT emulator: the kernel headers are included from where they
 // lie under /root/reference (by path, never copied into the repository).  TEST INFRASTRUCTURE ONLY (dev container; the reference tree does not
-// exist on the GPU box).  Compiled twice by oracle/Makefile:
+// exist on the GPU box).  Compiled three times by oracle/Makefile:
 //   -DREF_FLAVOUR_PLOC  src/Ploc++Kernel.h: SetupClusters, Ploc, SinglePassPloc driven by a restatement of the host loop (src/PLOC++Bvh.cpp:82-152) —
 //                       the reference's Ploc kernel cannot run on wave64 hardware (WarpSize is hard-coded to 32 for gfx950, src/Common.h:100-106), so this
 //                       is its only executable form here — and its CollapseToWide4Bvh (:364-465; host set-up src/PLOC++Bvh.cpp:154-190);
 //   -DREF_FLAVOUR_LBVH  src/TwoPassLbvhKernel.h: CollapseToWide4Bvh (:237-336; host set-up src/TwoPassLbvh.cpp:154-183).
+//   -DREF_FLAVOUR_HPLOC src/HplocKernel.h: SetupClusters + HPloc (host: src/Hploc.cpp:83-121).  This flavour exists to CHECK THE EMULATOR, not the oracle: the
+//                       same header also runs UNMODIFIED on the MI355X (oracle/_ref/HplocKernel*.co through oracle/ref_driver.cpp), and it speaks the
+//                       vocabulary the Ploc / SinglePassPloc kernels speak (__ballot, __shfl, __syncthreads, LDS atomicMin(u64), global atomicAdd / atomicExch).
+//                       tests/test_reference_kernels.py::test_emulator_matches_hardware_on_hploc compares emulator(HplocKernel.h) with hardware(HplocKernel.h)
+//                       on the golden meshes — topology hash, leaves, merged count — which validates the emulator's wave-operation / barrier / atomic
+//                       semantics on silicon and thereby the instrument behind the PLOC++ and collapse pins.  Compiled from a temporary copy with the three
+//                       probe-only edits of SURVEY.md Appendix A.3 (lock-step made explicit: a barrier after :116, the clear of :143 moved behind :181).
 // tools/make_golden.py writes what they compute for the golden meshes into tests/golden/reference_outputs.json, which pins the oracle's PLOC++
 // and collapse restatements.  Recipe: SURVEY.md Appendix A.3.
 //
@@ -100,6 +107,9 @@ inline uint64_t __ballot(int pred) { return emu::warpop(emu::OP_BALLOT, pred, 0)
 inline int __shfl(int v, int src) { return (int)emu::warpop(emu::OP_SHFL, v, src); }
 inline int __any(int pred) { return __ballot(pred) != 0; }      // (the collapse kernel of the same header; never launched here)
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+template <typename T, typename U> inline T atomicExch(T* p, U v) { const T old = *p; *p = (T)v; return old; }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
@@ -181,5 +191,28 @@ namespace { void entry_collapse() { CollapseToWide4Bvh(g_c.nodes, g_c.wide, g_c.
 // CollapseToWide4Bvh of the LBVH layout (src/TwoPassLbvhKernel.h:237-336).  nodes: Bvh2Node[2n-1]
 extern "C" int ref_emu_collapse_lbvh(void* nodes, uint32_t root, uint32_t n, void* wide_out, void* prims_out, uint32_t* n_wide_out) {
     return run_collapse(entry_collapse, nodes, nullptr, root, n, wide_out, prims_out, n_wide_out);
+}
+#endif
+
+#ifdef REF_FLAVOUR_HPLOC
+namespace {
+struct HArgs { Bvh2Node* nodes; PrimRef* leaves; u32* svals; Aabb* boxes; u32* skeys; u32* idx; u32* parent; u32* merged; u32 n; } g_h;
+void entry_hsetup() { SetupClusters(g_h.nodes, g_h.leaves, g_h.svals, g_h.boxes, g_h.idx, g_h.parent, g_h.n); }
+void entry_hploc() { HPloc(g_h.nodes, g_h.leaves, g_h.skeys, g_h.idx, g_h.parent, g_h.merged, g_h.n, g_h.n - 1); }
+}  // namespace
+// HPLOC::build from SetupClusters on (src/Hploc.cpp:83-121): nodeIdx0 / parentIdx all-invalid, SetupClusters over n threads, HPloc over ceil((n-1) / 32)
+// workgroups of 32 threads (cover_all: ceil(n / 32), so that leaf n-1 gets a thread when (n-1) % 32 == 0 — the reference under-launches).
+// Workgroups run one after another: a walker that arrives first at a node retires (atomicExch hand-off, :278-295), nobody waits for anybody.
+extern "C" int ref_emu_hploc(const void* boxes, const uint32_t* sorted_keys, const uint32_t* sorted_vals, uint32_t n, void* nodes_out, void* leaves_out,
+                             uint32_t* merged_out, int cover_all) {
+    if (n < 2) return -1;
+    std::vector<u32> idx(n, INVALID_NODE_IDX), parent(n, INVALID_NODE_IDX);
+    u32 merged = 0;
+    g_h = { (Bvh2Node*)nodes_out, (PrimRef*)leaves_out, const_cast<u32*>(sorted_vals), (Aabb*)const_cast<void*>(boxes), const_cast<u32*>(sorted_keys),
+            idx.data(), parent.data(), &merged, n };
+    launch_sequential(entry_hsetup, n, 256);
+    launch_sequential(entry_hploc, cover_all ? n : n - 1, HPlocBlockSize);
+    if (merged_out) *merged_out = merged;
+    return 0;
 }
 #endif
