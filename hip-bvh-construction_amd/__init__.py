@@ -62,7 +62,7 @@ EXPORTS = [
     "bvh_ctx_set_profiling", "bvh_ctx_kernel_times", "bvh_ctx_synchronize", "bvh_build", "bvh_build_ex", "bvh_stage_extents", "bvh_stage_extents_ex",
     "bvh_stage_morton", "bvh_stage_morton64", "bvh_stage_morton_plan", "bvh_sort_pairs", "bvh_sort_pairs64",
     "bvh_emit_lbvh_single", "bvh_emit_lbvh_two", "bvh_emit_ploc", "bvh_emit_hploc", "bvh_to_lbvh_layout", "bvh_collapse4", "bvh_generate_rays", "bvh_trace_while", "bvh_trace", "bvh_sah_cost",
-    "bvh_ctx_set_kernel_filter", "bvh_ctx_set_kernel_sampling", "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_destroy",
+    "bvh_ctx_set_kernel_filter", "bvh_ctx_set_kernel_sampling", "bvh_bvh4_cost", "bvh_checksum", "bvh_ctx_last_collapse_ms", "bvh_batch_create", "bvh_batch_build", "bvh_batch_download", "bvh_batch_destroy",
     "bvh_ctx_set_option", "bvh_ctx_get_option", "bvh_abi_version", "bvh_abi_struct_sizes",
     "bvh_download", "bvh_dev_alloc", "bvh_dev_free", "bvh_dev_upload", "bvh_dev_download", "bvh_dev_copy", "bvh_batched_build", "bvh_version",
 ]
@@ -85,14 +85,21 @@ class Result(C.Structure):
                 ("d_tris", C.c_void_p), ("d_morton_keys", C.c_void_p)]
 
 
+class BatchMesh(C.Structure):
+    """bvh_batch_mesh: where one mesh's tree lives after bvh_batch_build"""
+    _fields_ = [("device", C.c_int32), ("n_leaves", C.c_uint32), ("n_internal", C.c_uint32), ("n_nodes", C.c_uint32), ("root", C.c_uint32), ("layout", C.c_uint32),
+                ("d_nodes", C.c_void_p), ("d_leaves", C.c_void_p)]
+
+
 class BatchReport(C.Structure):
     """bvh_batch_report"""
     _fields_ = [("root_aabbs", C.POINTER(C.c_float)), ("build_ms", C.POINTER(C.c_float)), ("checksums", C.POINTER(C.c_uint64)),
-                ("sah", C.POINTER(C.c_double)), ("allgather_us", C.c_float), ("wall_ms", C.c_float)]
+                ("sah", C.POINTER(C.c_double)), ("allgather_us", C.c_float), ("wall_ms", C.c_float),
+                ("meshes", C.POINTER(BatchMesh)), ("lanes_per_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 TRI_PADDED64, TRI_PACKED36, TRI_INDEXED = 0, 1, 2
-ABI_VERSION = 3                      # BVH_ABI_VERSION of include/bvh_mi355x.h this binding was written against
+ABI_VERSION = 4                      # BVH_ABI_VERSION of include/bvh_mi355x.h this binding was written against
 # bvh_option (bvh_ctx_set_option) and the names this harness accepts for the values
 OPT_HPLOC_SCHEDULER, OPT_LBVH_SCHEDULER, OPT_SORT_TEST_KNOBS, OPT_PLOC_SCHEDULER = 0, 1, 2, 3
 _OPTION_IDS = {"hploc": OPT_HPLOC_SCHEDULER, "lbvh": OPT_LBVH_SCHEDULER, "sort_knobs": OPT_SORT_TEST_KNOBS, "ploc": OPT_PLOC_SCHEDULER}
@@ -165,7 +172,7 @@ def lib() -> C.CDLL:
         "bvh_ctx_set_kernel_sampling": ([vp, u32], i32),
         "bvh_batch_create": ([i32, C.POINTER(i32), C.POINTER(vp)], i32),
         "bvh_batch_build": ([vp, i32, C.POINTER(vp), C.POINTER(u32), i32, C.POINTER(BatchReport)], i32),
-        "bvh_batch_destroy": ([vp], None),
+        "bvh_batch_destroy": ([vp], None), "bvh_batch_download": ([vp, C.POINTER(BatchMesh), vp, vp], i32),
         "bvh_ctx_set_option": ([vp, i32, C.c_int64], i32), "bvh_ctx_get_option": ([vp, i32, C.POINTER(C.c_int64)], i32),
         "bvh_abi_version": ([], u32), "bvh_abi_struct_sizes": ([C.POINTER(u32)], None),
     }
@@ -484,15 +491,29 @@ class Batch:
         _check(lib().bvh_batch_create(len(devices), devs, C.byref(h)), "bvh_batch_create")
         self.handle = h
 
-    def build(self, meshes, algo: int = ALGO_HPLOC, checksums: bool = True, sah: bool = False) -> dict:
+    def build(self, meshes, algo: int = ALGO_HPLOC, checksums: bool = True, sah: bool = False, keep: bool = False) -> dict:
+        """keep: every mesh's tree stays on its device (bvh_batch_mesh records under "meshes"; read one back with download(m))"""
         m = len(meshes)
         arrs = [np.ascontiguousarray(t) for t in meshes]
         ptrs = (C.c_void_p * m)(*[a.ctypes.data for a in arrs]); counts = (C.c_uint32 * m)(*[a.shape[0] for a in arrs])
         roots = np.zeros((m, 6), dtype=np.float32); ms = np.zeros(m, dtype=np.float32); ck = np.zeros(m, dtype=np.uint64); sh = np.zeros(m, dtype=np.float64)
+        self._meshes = (BatchMesh * m)() if keep else None
         rep = BatchReport(roots.ctypes.data_as(C.POINTER(C.c_float)), ms.ctypes.data_as(C.POINTER(C.c_float)),
-                          ck.ctypes.data_as(C.POINTER(C.c_uint64)) if checksums else None, sh.ctypes.data_as(C.POINTER(C.c_double)) if sah else None, 0.0, 0.0)
+                          ck.ctypes.data_as(C.POINTER(C.c_uint64)) if checksums else None, sh.ctypes.data_as(C.POINTER(C.c_double)) if sah else None, 0.0, 0.0,
+                          C.cast(self._meshes, C.POINTER(BatchMesh)) if keep else None, 0, 0)
         _check(lib().bvh_batch_build(self.handle, algo, ptrs, counts, m, C.byref(rep)), "bvh_batch_build")
-        return {"root_aabbs": roots, "build_ms": ms, "checksums": ck, "sah": sh, "allgather_us": float(rep.allgather_us), "wall_ms": float(rep.wall_ms)}
+        out = {"root_aabbs": roots, "build_ms": ms, "checksums": ck, "sah": sh, "allgather_us": float(rep.allgather_us), "wall_ms": float(rep.wall_ms),
+               "lanes_per_device": int(rep.lanes_per_device)}
+        if keep:
+            out["meshes"] = [{f: getattr(self._meshes[i], f) for f, _ in BatchMesh._fields_} for i in range(m)]
+        return out
+
+    def download(self, m: int):
+        """bvh_batch_download of mesh m of the last build(keep=True): (nodes, leaves or None)"""
+        bm = self._meshes[m]
+        nodes = np.zeros(bm.n_nodes, dtype=BVH2_NODE); leaves = np.zeros(bm.n_leaves, dtype=PRIMREF) if bm.d_leaves else None
+        _check(lib().bvh_batch_download(self.handle, C.byref(bm), nodes.ctypes.data, leaves.ctypes.data if leaves is not None else None), "bvh_batch_download")
+        return nodes, leaves
 
     def close(self) -> None:
         if self.handle:

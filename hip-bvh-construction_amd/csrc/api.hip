@@ -293,7 +293,7 @@ uint64_t algorithmic_bytes(bvh_algo a, uint32_t n) {
 
 extern "C" {
 
-const char* bvh_version(void) { return "bvh_mi355x 0.3 (gfx950)"; }
+const char* bvh_version(void) { return "bvh_mi355x 0.4 (gfx950)"; }
 uint32_t bvh_abi_version(void) { return BVH_ABI_VERSION; }
 void bvh_abi_struct_sizes(uint32_t out[3]) { if (out) { out[0] = (uint32_t)sizeof(bvh_result); out[1] = (uint32_t)sizeof(bvh_timings); out[2] = (uint32_t)sizeof(bvh_build_input); } }
 

@@ -81,6 +81,11 @@ __device__ __forceinline__ u32 parent_gap(u32 L, u32 R, u32 ni, Closer pair_clos
     return pair_closer(R, L - 1u) ? R : L - 1u;
 }
 
+// Survivor records of a finished range [L, R] (> 16 leaves): sixteen 32-byte records inside the range's own positions of `recs`.  Round 4: a range that is the LEFT
+// child of its parent (parent gap == R) stores them at its LAST sixteen positions, a right child at its first sixteen — both children's records then sit around the
+// parent's split p ([p - 15, p] and [p + 1, p + 16]) and are addressable from p alone, before the parent's range is known (k_hploc_ext's look-ahead).
+__device__ __forceinline__ u32 rec_base(bool left_child, u32 L, u32 R) { return left_child ? R - (HP_HALF - 1u) : L; }
+
 struct HpWork { u32 id, rep, cnt, tL; Box b; bool have, final_; };
 
 // loadIndices (:192-206) + the box fetch of plocMerge (:242-246): slots 0..15 <- left child [tL, tP], 16..31 <- right child
@@ -105,7 +110,7 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
         } else b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1));
     }
-    if (have && c_len > HP_HALF) rec_load_agent(recs + c_start + s, id, rep, b);
+    if (have && c_len > HP_HALF) rec_load_agent(recs + rec_base(is_left, c_start, tP) + s, id, rep, b);     // (left child [tL, tP]: right-aligned at tP; right child: at tP + 1)
     // left-pack: slot t < nl <- slot t ; slot t in [nl, cnt) <- slot 16 + (t - nl)
     const u32 vb = (u32)(__ballot(id != INV) >> hbase);
     const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
@@ -508,7 +513,8 @@ __device__ __forceinline__ void climb_pass(u64 rm, bool& ready, u32& pc, u32& L,
         HpWork w = load_work<SETUP>(have, tL, tR, tP, boxes, svals, leaves, recs, ni, slot, hbase);
         ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn);
         // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated
-        if (have && !w.final_ && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);
+        const bool left_child = __shfl((int)(q == R), osrc) != 0;      // (the owner's q: this range is its parent's left child)
+        if (have && !w.final_ && slot < 16) node_store_agent(recs + rec_base(left_child, tL, tR) + slot, w.id, w.rep, w.b);
 
         if (owner) {
             ready = false;
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 const u32 sp = Lr + (u32)sl;
                 TileList::Tag tg; Box b;
                 tl.load(sp, tg, b);
-                node_store_plain(recs + L + sl, TileList::is_valid(tg) ? tl.id(tg) : INV, tl.rep(tg), b);     // read by k_hploc_ext: the kernel boundary orders it
+                node_store_plain(recs + rec_base(!right, L, R) + sl, TileList::is_valid(tg) ? tl.id(tg) : INV, tl.rep(tg), b);     // read by k_hploc_ext: the kernel boundary orders it
             }
             if (on && sl == 0) {                     // lane 0 of each group moves the parent's count
                 const u32 q = right ? L - 1u : R;
@@ -1056,7 +1062,7 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     if (carried) { id = cid; rep = crep; b = cb; }
     const bool leaf = have && !carried && c_len <= HP_HALF && s < c_len;
     if (leaf) { rep = c_start + s; id = ni + rep; b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1)); }
-    if (have && !carried && c_len > HP_HALF) rec_load_agent(recs + c_start + s, id, rep, b);
+    if (have && !carried && c_len > HP_HALF) rec_load_agent(recs + rec_base(is_left, c_start, tP) + s, id, rep, b);
     const u32 vb = (u32)(__ballot(id != INV) >> hbase);
     const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
     HpWork w; w.cnt = nl + nr; w.tL = tL; w.have = have; w.final_ = have && tL == 0 && tR == ni;
@@ -1104,7 +1110,8 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     }
     const bool hfast = __shfl((int)fast, hbase) != 0;
     // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated — unless they stay in registers
-    if (have && !w.final_ && !hfast && slot < 16) node_store_agent(recs + tL + slot, w.id, w.rep, w.b);
+    const bool left_child = __shfl((int)(q == R), hbase) != 0;        // (the owner's q and R: this range is its parent's left child)
+    if (have && !w.final_ && !hfast && slot < 16) node_store_agent(recs + rec_base(left_child, tL, tR) + slot, w.id, w.rep, w.b);
 #ifdef ABL_EXT_NOCLIMB   // in-situ probe: every queue item runs its first task only (how much of k_hploc_ext is throughput, how much the climb?)
     if (owner) { ready = false; cw.side = 0; }
     if (owner && false) {

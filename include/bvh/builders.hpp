@@ -229,6 +229,9 @@ public:
     DeviceView<uint64_t> d_mortonCodeKeys64, d_sortedMortonCodeKeys64;     // 60-bit builds (beyond the reference)
     DeviceView<Bvh2Node> d_bvhNodes;
     DeviceView<PrimRef> d_leafNodes;
+    DeviceView<u32> d_flags;             // src/TwoPassLbvh.h:27, src/SinglePassLbvh.h:27: the reference's refit counters (scratch of its BvhBuild / FitBvhNodes launches).  This
+                                         // pipeline's parent-claim words are self-cleaning context scratch with another meaning, so the view is EMPTY (size() == 0): a host that
+                                         // names the member compiles, one that reads counters out of it gets none
     u32 m_rootNodeIdx = 0;
     Timer m_timer;
     u32 m_nInternalNodes = 0;
@@ -245,6 +248,42 @@ public:
 
 // src/BatchedBuilder.h:12-31, re-purposed as the scene shard of BASELINE.json config 5: one mesh per GPU, RCCL all-gather of roots.
 // The per-device contexts and the communicator live as long as the object (bvh_batch).
+// every mesh's array of one kind (nodes or leaves), each on the device that built the mesh: what the reference keeps in ONE Oro::GpuMemory (src/BatchedBuilder.h:24-25)
+template <typename T> class BatchView {
+public:
+    struct Segment { int device; const T* ptr; size_t count; };
+    void clear() { m_seg.clear(); m_batch = nullptr; }
+    void bind(bvh_batch* b, const std::vector<bvh_batch_mesh>* meshes, bool leaves) {
+        m_batch = b; m_meshes = meshes; m_leaves = leaves; m_seg.clear();
+        for (const auto& m : *meshes) m_seg.push_back(Segment{m.device, static_cast<const T*>(leaves ? m.d_leaves : m.d_nodes), leaves ? (m.d_leaves ? size_t(m.n_leaves) : 0) : size_t(m.n_nodes)});
+    }
+    size_t size() const { size_t t = 0; for (const auto& s : m_seg) t += s.count; return t; }      // all meshes together
+    size_t meshes() const { return m_seg.size(); }
+    const Segment& segment(size_t m) const { return m_seg[m]; }                                    // mesh m's part (device pointer valid on segment(m).device)
+    T* ptr() const { return m_seg.empty() ? nullptr : const_cast<T*>(m_seg[0].ptr); }              // mesh 0's part
+    std::vector<T> getData(size_t m) const {                                                       // one mesh
+        std::vector<T> h(m_seg[m].count);
+        if (!h.empty()) check(bvh_batch_download(m_batch, &(*m_meshes)[m], m_leaves ? nullptr : h.data(), m_leaves ? h.data() : nullptr), "bvh_batch_download");
+        return h;
+    }
+    std::vector<T> getData() const {                                                               // concatenated in mesh order, like the reference's single array
+        std::vector<T> all; all.reserve(size());
+        for (size_t m = 0; m < m_seg.size(); ++m) { const auto part = getData(m); all.insert(all.end(), part.begin(), part.end()); }
+        return all;
+    }
+private:
+    bvh_batch* m_batch = nullptr; const std::vector<bvh_batch_mesh>* m_meshes = nullptr; bool m_leaves = false; std::vector<Segment> m_seg;
+};
+// d_rootNodes: one root index per mesh (host-resident here: the indices are known to the host the moment a build returns)
+class RootView {
+public:
+    void assign(std::vector<u32> v) { m_v = std::move(v); }
+    u32* ptr() const { return nullptr; }
+    size_t size() const { return m_v.size(); }
+    std::vector<u32> getData() const { return m_v; }
+private:
+    std::vector<u32> m_v;
+};
 struct BatchedBuildInput { std::vector<Triangle> m_primitives; };
 class BatchedBvhBuilder {
 public:
@@ -256,18 +295,46 @@ public:
         std::vector<const void*> ptrs; std::vector<uint32_t> counts;
         for (auto& b : batch) { ptrs.push_back(b.m_primitives.data()); counts.push_back((uint32_t)b.m_primitives.size()); }
         m_rootAabbs.assign(batch.size(), Aabb{}); m_buildMs.assign(batch.size(), 0.f); m_checksums.assign(batch.size(), 0);
+        m_sah.assign(batch.size(), 0.0); m_meshes.assign(batch.size(), bvh_batch_mesh{});
         bvh_batch_report rep{}; rep.root_aabbs = reinterpret_cast<float*>(m_rootAabbs.data()); rep.build_ms = m_buildMs.data(); rep.checksums = m_checksums.data();
+        rep.sah = m_sah.data(); rep.meshes = m_meshes.data();
         check(bvh_batch_build(m_batch, m_algo, ptrs.data(), counts.data(), (int)batch.size(), &rep), "bvh_batch_build");
-        m_allGatherUs = rep.allgather_us; m_wallMs = rep.wall_ms;
+        m_allGatherUs = rep.allgather_us; m_wallMs = rep.wall_ms; m_lanesPerDevice = rep.lanes_per_device;
+        // the reference's members (src/BatchedBuilder.h:24-30)
+        d_bvhNodes.bind(m_batch, &m_meshes, false); d_primRefs.bind(m_batch, &m_meshes, true);
+        std::vector<u32> roots; size_t off = 0; m_nInternalNodes = 0; double cost = 0; float dev_ms = 0.f;
+        std::vector<float> per_dev(m_devices.size(), 0.f);
+        for (size_t m = 0; m < m_meshes.size(); ++m) {
+            roots.push_back(u32(off + m_meshes[m].root)); off += m_meshes[m].n_nodes;               // index into the concatenated d_bvhNodes.getData()
+            m_nInternalNodes += m_meshes[m].n_internal; cost += m_sah[m];
+            per_dev[m % m_devices.size()] += m_buildMs[m];
+        }
+        for (float v : per_dev) dev_ms = v > dev_ms ? v : dev_ms;
+        d_rootNodes.assign(roots);
+        m_rootNodeIdx = roots.empty() ? 0u : roots[0];
+        m_cost = m_meshes.empty() ? 0.f : float(cost / double(m_meshes.size()));
+        m_timer.set(BvhBuildTime, dev_ms);
     }
     void traverseBvh(Context&) {   // (the reference's flavour renders one of its tiny trees; here: the per-mesh report)
         for (size_t m = 0; m < m_buildMs.size(); ++m) std::cout << "mesh " << m << " build " << m_buildMs[m] << "ms" << std::endl;
         std::cout << "root AABB all-gather " << m_allGatherUs << "us" << std::endl;
     }
+    // the reference's public members (src/BatchedBuilder.h:24-30).  Child indices inside a mesh's nodes are mesh-local; d_rootNodes[m] is mesh m's root as an index
+    // into the concatenated getData() of d_bvhNodes (= the mesh's node offset + its local root)
+    BatchView<Bvh2Node> d_bvhNodes;     // every mesh's Bvh2Node array (PLOC layouts: n-1 internal nodes; LBVH: 2n-1 with the leaves inside)
+    BatchView<PrimRef> d_primRefs;      // every mesh's PrimRef leaves (PLOC layouts; empty for the LBVH builders)
+    RootView d_rootNodes;
+    u32 m_rootNodeIdx = 0;              // = d_rootNodes[0]
+    Timer m_timer;                      // BvhBuildTime: device time of the batch = max over devices of the sum of its meshes' E+M+S+B
+    u32 m_nInternalNodes = 0;           // of all meshes together
+    float m_cost = 0.0f;                // mean BVH2 SAH cost of the batch's meshes (the reference never sets it)
+    // beyond the reference's members
     std::vector<Aabb> m_rootAabbs;      // TLAS input: one root box per mesh, identical on every device after the all-gather
     std::vector<float> m_buildMs;
     std::vector<uint64_t> m_checksums;  // bvh_checksum of every mesh's tree
-    float m_allGatherUs = 0.f, m_wallMs = 0.f;
+    std::vector<double> m_sah;
+    std::vector<bvh_batch_mesh> m_meshes;
+    float m_allGatherUs = 0.f, m_wallMs = 0.f; int m_lanesPerDevice = 0;
 private:
     std::vector<int> m_devices; bvh_algo m_algo; bvh_batch* m_batch = nullptr;
 };

@@ -227,6 +227,14 @@ int  bvh_batched_build(int n_dev, const int* devs, bvh_algo algo, const void* co
 /* The same as a reusable object: the per-device contexts (arenas), the RCCL communicator and the gather buffers are created once and
  * kept across builds (bvh_batched_build pays for them on every call).  Report fields are optional except root_aabbs. */
 typedef struct bvh_batch bvh_batch;
+/* where one mesh's tree lives after bvh_batch_build (the reference's BatchedBvhBuilder keeps every mesh's nodes and leaves on the device: d_bvhNodes / d_primRefs /
+ * d_rootNodes, src/BatchedBuilder.h:24-26).  Device memory owned by the batch, valid until its next build or bvh_batch_destroy; child indices are mesh-local. */
+typedef struct {
+    int32_t     device;        /* HIP device the arrays live on */
+    uint32_t    n_leaves, n_internal, n_nodes, root, layout;   /* as bvh_result; n_nodes = Bvh2Node records at d_nodes (layout 0: 2n-1, layout 1: n-1) */
+    const void* d_nodes;       /* Bvh2Node[n_nodes] */
+    const void* d_leaves;      /* PrimRef[n_leaves] (layout 1) or NULL (layout 0: the leaves are nodes n-1 .. 2n-2) */
+} bvh_batch_mesh;
 typedef struct {
     float*    root_aabbs;      /* [6 * n_meshes] min xyz, max xyz per mesh, as all-gathered (device devs[0]'s copy) */
     float*    build_ms;        /* [n_meshes] or NULL: E+M+S+B per mesh (stage events) */
@@ -234,9 +242,16 @@ typedef struct {
     double*   sah;             /* [n_meshes] or NULL: bvh_sah_cost of each mesh's tree */
     float     allgather_us;    /* out: duration of the RCCL all-gather of the root boxes (HIP events, max over devices) */
     float     wall_ms;         /* out: host wall time of the call (H2D copies of the inputs included) */
+    bvh_batch_mesh* meshes;    /* [n_meshes] or NULL: every mesh's tree is copied out of its context's arena and kept (ABI 4) */
+    int32_t   lanes_per_device;/* out: contexts (streams + host threads) each device pipelined its meshes on: min(3, meshes per device) (ABI 4) */
+    int32_t   reserved;
 } bvh_batch_report;
 int  bvh_batch_create(int n_dev, const int* devs, bvh_batch** out);
+/* mesh m is built on devs[m % n_dev]; a device that holds several meshes pipelines them on up to three contexts (H2D of one mesh, build of another, checksum /
+ * tree copy of a third overlap); one ncclAllGather of the root boxes at the end.  Blocking. */
 int  bvh_batch_build(bvh_batch* batch, bvh_algo algo, const void* const* h_tris, const uint32_t* n_tris, int n_meshes, bvh_batch_report* report);
+/* read one kept tree back (h_nodes: Bvh2Node[n_nodes], h_leaves: PrimRef[n_leaves] or NULL) */
+int  bvh_batch_download(bvh_batch* batch, const bvh_batch_mesh* mesh, void* h_nodes, void* h_leaves);
 void bvh_batch_destroy(bvh_batch* batch);
 
 /* wait for everything enqueued on the ctx's stream (bvh_build is asynchronous unless it has to read something back:
@@ -256,8 +271,9 @@ int  bvh_dev_copy(bvh_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);
 const char* bvh_version(void);
 /* ABI revision of this header (BVH_ABI_VERSION): bumped whenever a struct of this file changes size or an entry point changes signature, so that a host
  * compiled against an older header can refuse to run instead of handing the library a too-small bvh_result.  Revision 3: bvh_result carries d_tris and
- * d_morton_keys (88 bytes; round 2 grew it without a bump), bvh_ctx_set_option / bvh_ctx_get_option exist. */
-#define BVH_ABI_VERSION 3
+ * d_morton_keys (88 bytes; round 2 grew it without a bump), bvh_ctx_set_option / bvh_ctx_get_option exist.  Revision 4: bvh_batch_report carries `meshes`
+ * and `lanes_per_device` (56 bytes), bvh_batch_mesh / bvh_batch_download / bvh_stage_morton_plan exist. */
+#define BVH_ABI_VERSION 4
 uint32_t bvh_abi_version(void);
 /* sizeof(bvh_result) / sizeof(bvh_timings) / sizeof(bvh_build_input) as the LIBRARY was compiled: out[0..2] */
 void bvh_abi_struct_sizes(uint32_t out[3]);

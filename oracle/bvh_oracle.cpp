@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cfloat>
 #include <queue>
 #include <vector>
 
@@ -101,7 +102,17 @@ MortonPlan morton_plan(const F3& e, const u32 NB = 30) {   // NB: bit budget —
     MortonPlan m;
     const float ext[3] = { e.x, e.y, e.z };
     int px, py, pz;
-    auto lg = [](float num, float den) { return sat_f2i(log2f(num / den)); };
+    // (int)log2f(ratio), :175-248.  The reference evaluates it on the DEVICE: OCML's log2f (v_log_f32: exponent + log2(mantissa), the fraction always < 1) never
+    // rounds a ratio just below 2^k up to k, whereas a correctly rounded host log2f does from k = 2 on (log2(2^k (1 - 2^-24)) = k - 8.6e-8 is nearer to k than to the
+    // float below k).  Measured on the MI355X (tests/test_gpu_round4.py::test_morton_plan_at_log2_boundaries, round 4): with the host's libm here, 228 of 720 scenes whose
+    // extent ratios sit 1-2 ulp below a power of two got a different bit plan than the reference's own CalculateMortonCodes kernel; the truncated value the device
+    // produces is the exact floor, i.e. the ratio's binary exponent.  So: finite ratios >= 1 (the if-chain below always divides the larger extent by the smaller)
+    // take ilogbf; everything else (a zero extent: inf or NaN) goes through log2f and the saturating conversion as before.
+    auto lg = [](float num, float den) {
+        const float r = num / den;
+        if (r >= 1.0f && r <= FLT_MAX) return (int)ilogbf(r);
+        return sat_f2i(log2f(r));
+    };
     // literal if-chain of :167-250 (strict '<' comparisons decide tie order)
     if (e.x < e.y) {
         if (e.x < e.z) {

@@ -29,10 +29,11 @@ def test_abi_revision_and_struct_sizes(pkg):
     revision and the sizes it was compiled with; the binding refuses to load a mismatch (pkg.lib())"""
     L = pkg.lib()
     hdr = open(os.path.join(ROOT, "include", "bvh_mi355x.h")).read()
-    assert int(re.search(r"#define\s+BVH_ABI_VERSION\s+(\d+)", hdr).group(1)) == L.bvh_abi_version() == pkg.ABI_VERSION == 3
+    assert int(re.search(r"#define\s+BVH_ABI_VERSION\s+(\d+)", hdr).group(1)) == L.bvh_abi_version() == pkg.ABI_VERSION == 4
     sizes = (C.c_uint32 * 3)(); L.bvh_abi_struct_sizes(sizes)
     assert tuple(sizes) == (C.sizeof(pkg.Result), C.sizeof(pkg.Timings), C.sizeof(pkg.BuildInput)) == (88, 40, 40)
-    assert b"0.3" in L.bvh_version()
+    assert b"0.4" in L.bvh_version()
+    assert C.sizeof(pkg.BatchReport) == 56 and C.sizeof(pkg.BatchMesh) == 40      # (ABI 4; not covered by bvh_abi_struct_sizes: the revision number guards them)
 
 
 def test_library_reads_no_environment(pkg):
@@ -52,7 +53,7 @@ def test_version_and_no_cpu_fallback(pkg):
 
 
 def test_struct_layouts(pkg):
-    assert C.sizeof(pkg.Result) == 6 * 8 + 6 * 4 + 2 * 8 and C.sizeof(pkg.BatchReport) == 4 * 8 + 2 * 4 and C.sizeof(pkg.BuildInput) == 2 * 4 + 3 * 8 + 2 * 4 and C.sizeof(pkg.Timings) == 6 * 4 + 2 * 4 + 8
+    assert C.sizeof(pkg.Result) == 6 * 8 + 6 * 4 + 2 * 8 and C.sizeof(pkg.BatchReport) == 4 * 8 + 2 * 4 + 8 + 2 * 4 and C.sizeof(pkg.BuildInput) == 2 * 4 + 3 * 8 + 2 * 4 and C.sizeof(pkg.Timings) == 6 * 4 + 2 * 4 + 8
     assert pkg.TRIANGLE.itemsize == 64 and pkg.BVH2_NODE.itemsize == 32 and pkg.PRIMREF.itemsize == 28 and pkg.AABB.itemsize == 24
 
 

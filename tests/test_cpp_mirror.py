@@ -99,3 +99,6 @@ def test_batched_builder_mirror(driver, mesh_files):
     r = subprocess.run([driver, "batched", mesh_files["uniform30k"]], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all-gather" in r.stdout and r.stdout.count("mesh ") == 4
+    # the reference's public members (src/BatchedBuilder.h:24-30: d_bvhNodes / d_primRefs / d_rootNodes, m_rootNodeIdx, m_timer, m_nInternalNodes, m_cost) are read by
+    # the driver itself (it exits non-zero if a root node is not where d_rootNodes says); four 30 000-triangle HPLOC meshes on one device: 4 x 29 999 nodes, 3 lanes
+    assert "batched: 119996 nodes, 120000 leaves" in r.stdout and "lanes per device" in r.stdout

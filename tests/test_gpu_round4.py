@@ -34,16 +34,18 @@ def _ulps(x, d):
 
 
 def test_morton_plan_at_log2_boundaries(pkg, orc, ctx):
-    """`numPrebits = (int)log2f(extent ratio)` (src/CommonBlocksKernel.h:175-248) is evaluated by the DEVICE's log2f in the reference and in the product, by the
-    host's libm in the CPU oracle (SURVEY.md section 7 flagged it).  Scenes whose extent ratios are 2^k * (1 - 2 ulp .. 1 + 2 ulp), k = 1..12, on every axis order:
-      * product == the reference's own CalculateMortonCodes kernel on the MI355X, key for key, on EVERY scene (that is the parity that counts);
-      * the device's plan (bvh_stage_morton_plan) == the oracle's plan wherever host and device log2f truncate alike, and where they do not, the oracle's encoder
-        driven by the device's plan reproduces the reference's keys: the log2f truncation is the ONLY difference."""
+    """`numPrebits = (int)log2f(extent ratio)` (src/CommonBlocksKernel.h:175-248) is evaluated by the DEVICE's log2f in the reference and in the product; SURVEY.md
+    section 7 flagged that a host libm may truncate differently.  Scenes whose extent ratios are 2^k * (1 - 2 ulp .. 1 + 2 ulp), k = 1..30, on every axis order:
+      * product == the reference's own CalculateMortonCodes kernel on the MI355X, key for key, on EVERY scene (the parity that counts);
+      * the device's plan (bvh_stage_morton_plan) == the oracle's plan and the oracle's keys == the reference's on every scene.  Round 4 measured this test with the
+        oracle calling the host's log2f: 228 of 720 scenes (every ratio 1-2 ulp below 2^k, k >= 2) got a different plan — the device's log2f never rounds up to k, a
+        correctly rounded one does — and the oracle's encoder driven by the device's plan reproduced the reference's keys on all of them: the truncation was the only
+        difference.  The oracle now takes the exact floor (the ratio's binary exponent; oracle/bvh_oracle.cpp morton_plan), which is what the device computes."""
     require_ref(os.path.exists(orc.REF_DRIVER), "oracle/_ref/libref_driver.so (the reference's kernels)")
     L = pkg.lib()
     scenes = 0; plan_diff = []
     for perm in itertools.permutations(range(3)):
-        for k in range(1, 13):
+        for k in range(1, 31):
             for d in (-2, -1, 0, 1, 2):
                 r = _ulps(np.float32(2.0) ** k, d)
                 # family A: (r, 1, 1): the a0 / a1 and a0 / a2 ratios sit on the boundary; family B: (2 r, r, 1): a1 / a2 does
@@ -62,17 +64,18 @@ def test_morton_plan_at_log2_boundaries(pkg, orc, ctx):
                     plan_dev = list(plan)
                     po = orc.morton_plan(scene)
                     plan_orc = po["axis"] + po["bits"] + po["pre"] + [po["pre_sum"], po["swap"]]
-                    if plan_dev == plan_orc:
-                        assert np.array_equal(orc.morton_codes(boxes, scene)[0], keys_ref), f"oracle != reference at extents {e} on axes {perm} although the plans agree"
-                    else:
+                    if plan_dev != plan_orc:
                         plan_diff.append((perm, k, d, plan_dev, plan_orc))
-                        assert plan_dev[0:3] == plan_orc[0:3], "axis order does not depend on log2f"
                         assert np.array_equal(orc.morton_codes_with_plan(boxes, scene, plan_dev), keys_ref), "oracle encoder with the device's plan != reference"
+                    else:
+                        assert np.array_equal(orc.morton_codes(boxes, scene)[0], keys_ref), f"oracle != reference at extents {e} on axes {perm} although the plans agree"
+                    for b in (d_box, d_scene, d_keys):
+                        b.free()
                     scenes += 1
-    print(f"\n{scenes} boundary scenes: product == reference kernel on all; host libm and device log2f truncate differently on {len(plan_diff)}")
+    print(f"\n{scenes} boundary scenes: product == reference kernel on all; oracle plan != device plan on {len(plan_diff)}")
     for x in plan_diff[:8]:
-        print("   axes %s  2^%d %+d ulp: device plan %s, host plan %s" % x)
-    # host and device may disagree only ON the boundary (|d| <= 2 ulp was all that was generated); a disagreement elsewhere would have failed above
+        print("   axes %s  2^%d %+d ulp: device plan %s, oracle plan %s" % x)
+    assert not plan_diff, "the oracle's (int)log2f differs from the device's"
 
 
 def test_collapse_hints_do_not_leak_between_different_trees_of_one_size(pkg, orc, ctx):
@@ -98,3 +101,54 @@ def test_collapse_hints_do_not_leak_between_different_trees_of_one_size(pkg, orc
         for cls, mesh in seq:
             wide, prims, nw = cls().build(ctx, mesh).collapse4()
             assert (nw, orc.topology_hash4(wide, prims, nw, n)) == fresh[(cls.__name__, mesh is uni)]
+
+
+def test_batch_keeps_every_mesh_and_pipelines_a_device(pkg, orc, ctx):
+    """VERDICT r03 items 6 and 8.  (a) keep=True: every mesh's tree stays on its device (bvh_batch_mesh; the reference's d_bvhNodes / d_primRefs / d_rootNodes) and
+    equals the tree of a single build; (b) a device that holds several meshes pipelines them on up to three contexts — H2D of one mesh, build of another, checksum /
+    copy of a third overlap — and the result is the same as with the meshes built one after another.  Prints the aggregate rate from wall_ms for both."""
+    import torch
+    devs = tuple(range(torch.cuda.device_count()))
+    meshes = [pkg.meshgen.uniform(2_000_000, 100 + m, offset=(float(m), 0.0, 0.0)) for m in range(8)]       # config 5's shape
+    total = sum(len(t) for t in meshes)
+    batch = pkg.Batch(devs)
+    try:
+        batch.build(meshes, pkg.ALGO_HPLOC, checksums=True)                                                    # (arenas, staging buffers and lanes get created)
+        rep = batch.build(meshes, pkg.ALGO_HPLOC, checksums=True, sah=True, keep=True)
+        assert rep["lanes_per_device"] == min(3, -(-len(meshes) // len(devs)))
+        for m in (0, 3, 7):
+            nodes, leaves = batch.download(m)
+            bm = rep["meshes"][m]
+            assert bm["n_leaves"] == len(meshes[m]) and bm["n_nodes"] == len(meshes[m]) - 1 and bm["layout"] == 1 and bm["root"] == 0
+            assert pkg.checksum_host(nodes, leaves, 0) == int(rep["checksums"][m])
+            single = pkg.HPLOC().build(ctx, meshes[m])
+            assert single.checksum() == int(rep["checksums"][m])
+            _, scene = orc.prim_bounds(meshes[m])
+            assert np.array_equal(nodes[0]["min"], scene["min"][0]) and np.array_equal(nodes[0]["max"], scene["max"][0])
+        walls = [batch.build(meshes, pkg.ALGO_HPLOC, checksums=True)["wall_ms"] for _ in range(3)]
+        # the strictly serial form for comparison: one mesh per call
+        t_serial = []
+        for _ in range(2):
+            w = 0.0
+            for t in meshes:
+                w += batch.build([t], pkg.ALGO_HPLOC, checksums=True)["wall_ms"]
+            t_serial.append(w)
+        print("\nconfig-5 batch on %d device(s), %d lanes per device: wall %.1f ms = %.0f Mtris/s (host buffers, H2D included); one mesh per call: %.1f ms = %.0f Mtris/s"
+              % (len(devs), rep["lanes_per_device"], min(walls), total / min(walls) / 1e3, min(t_serial), total / min(t_serial) / 1e3))
+        if len(devs) == 1:
+            assert min(walls) < min(t_serial), "pipelining a device's meshes should not be slower than building them one call at a time"
+    finally:
+        batch.close()
+    # LBVH algos keep 2n-1 nodes and no leaf array
+    small = [pkg.meshgen.uniform(5000 + 11 * m, 7 + m) for m in range(3)]
+    b2 = pkg.Batch(devs[:1])
+    try:
+        r2 = b2.build(small, pkg.ALGO_SINGLEPASS, checksums=True, keep=True)
+        for m, t in enumerate(small):
+            nodes, leaves = b2.download(m)
+            assert leaves is None and len(nodes) == 2 * len(t) - 1
+            fe = orc.front_end(t)
+            o_nodes, o_root = orc.lbvh_single(t, fe["skeys"], fe["svals"])
+            assert r2["meshes"][m]["root"] == o_root and nodes.tobytes() == o_nodes.tobytes()
+    finally:
+        b2.close()

@@ -112,4 +112,5 @@ def test_emulator_matches_hardware_on_hploc(pkg, orc, drv, kind, n, seed):
     assert e_leaves.tobytes() == h_leaves.tobytes()
     assert orc.validate_bvh2(e_nodes, e_leaves, 0, n, 1) == 0 and orc.validate_bvh2(h_nodes, h_leaves, 0, n, 1) == 0
     assert orc.topology_hash(e_nodes, e_leaves, 0, n, 1) == orc.topology_hash(h_nodes, h_leaves, 0, n, 1), "emulated HPloc != HPloc on the MI355X"
-    assert orc.sah_bvh2(e_nodes, e_leaves, 0, n, 1)[0] == orc.sah_bvh2(h_nodes, h_leaves, 0, n, 1)[0]
+    # (node NUMBERING is schedule dependent — global atomicAdd, src/HplocKernel.h:165-168 — and the f64 cost sums in node order: equal up to the summation order)
+    assert orc.sah_bvh2(e_nodes, e_leaves, 0, n, 1)[0] == pytest.approx(orc.sah_bvh2(h_nodes, h_leaves, 0, n, 1)[0], rel=1e-12)
