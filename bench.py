@@ -11,7 +11,11 @@ Also reported on the same JSON line:
   roofline     — dominant kernel's algorithmic bytes / its HIP-event time (events recorded on the launch stream inside the
                  timed region) against the 8 TB/s HBM peak; roofline.issue = how busy the VALUs and the LDS pipe are in that kernel
                  (from the committed counter file profiles/issue_counters.json: the second bound of a kernel that is not HBM-bound);
-  cpu_baseline — the reference's CPU binned-SAH builder (oracle port, 1 thread) timed on a bounded sample of the same mesh.
+  cpu_baseline — the reference's CPU binned-SAH builder (oracle port, 1 thread) timed on a bounded sample of the same mesh;
+  secondary    — (N = 1) the other BASELINE.json configs at their own sizes, 50-build loops after the timed region: Sponza-class 262 144 single-pass LBVH (config 2),
+                 Sponza-class 262 144 PLOC++ + the BVH4 collapse (config 4), uniform 2 M HPLOC (config 5's per-GPU mesh), each with the FIRST build of that size on a
+                 fresh context beside the warm loop (the library sizes some launch batches from the previous same-size build);
+  config5      — (N > 1) the same exchange with config 5's own shape: 2 M triangles per GPU, seed 100 + rank, offset (rank, 0, 0).
 Algorithmic bytes of the PLOC-family emit stages are exact per mesh: profiles/algorithmic_bytes.json, written by
 tools/algorithmic_bytes.py from the pinned oracle's cluster-load / store counts; the split of the HPLOC emit between its two kernels is the
 measured task share of profiles/hploc_task_share.json (tools/measure_task_share.py).  Both are data files: nothing here calls the oracle outside
@@ -62,6 +66,65 @@ def _load_json(name):
         return None
 
 
+def kernel_source_hash() -> str:
+    """sha256[:16] over the kernel sources: the committed counter files (profiles/*.json written by tools/prof_round.sh) carry the hash of the sources they were
+    measured on, so that a line can say whether its static inputs (PMC traffic, SQ counters, task share) belong to the kernels it timed"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hip-bvh-construction_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run_secondary(pkg, torch, local):
+    """The other BASELINE.json configs at their own sizes (N = 1 only; after the timed region, before the CPU baseline): warm 50-build loops + the cold first build."""
+    import ctypes as C
+    out = []
+    specs = [("sponza_262144_tris_lbvh_single", pkg.ALGO_SINGLEPASS, lambda: pkg.meshgen.sponza_like(262_144, 3), 420.0, False),
+             ("sponza_262144_tris_ploc", pkg.ALGO_PLOCPP, lambda: pkg.meshgen.sponza_like(262_144, 3), None, True),
+             ("uniform_2000000_tris_hploc", pkg.ALGO_HPLOC, lambda: pkg.meshgen.uniform(2_000_000, 100), None, False)]
+    for workload, algo, gen, const_bytes, with_collapse in specs:
+        tris = gen(); n = len(tris)
+        d_tris = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()
+        ctx = pkg.Context(local)                                   # a FRESH context: nothing is known about this size
+        try:
+            ctx.reserve(n)                                          # (allocation is outside every timer, as in the headline loop)
+            b = pkg.BUILDERS[algo]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); b.build(ctx, d_tris, on_device=True, n=n); ctx.synchronize(); cold = (time.perf_counter() - t0) * 1e3
+            cold_collapse = None
+            if with_collapse:
+                ctx.set_profiling(1); b.build(ctx, d_tris, on_device=True, n=n); _, _, cold_collapse = b.collapse4_cost(); ctx.set_profiling(0)
+            for _ in range(5):
+                b.build(ctx, d_tris, on_device=True, n=n)
+            ctx.synchronize()
+            steps = 50
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b.build(ctx, d_tris, on_device=True, n=n)
+            ctx.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            ex = exact_bytes(workload)
+            per_prim = ex[2] if ex else const_bytes
+            e = {"workload": workload, "builder": pkg.ALGO_NAMES[algo], "tris": n, "steps": steps, "ms_per_step": round(ms, 4), "Mtris/s": round(n / ms / 1e3, 1),
+                 "pipeline_bytes_per_prim": per_prim, "pipeline_frac": round(per_prim * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if per_prim else None,
+                 "cold_first_build_ms": round(cold, 4)}
+            if with_collapse:
+                ctx.set_profiling(1)
+                cms = []
+                for _ in range(10):
+                    b.build(ctx, d_tris, on_device=True, n=n); cms.append(b.collapse4_cost()[2])
+                ctx.set_profiling(0)
+                e["bvh_collapse4_ms"] = round(float(np.median(cms)), 4); e["cold_collapse4_ms"] = round(float(cold_collapse), 4)
+            ctx.set_profiling(1); b.build(ctx, d_tris, on_device=True, n=n); e["stage_ms"] = {k: round(v, 4) for k, v in dict(b.m_timer).items()}; ctx.set_profiling(0)
+            out.append(e)
+        finally:
+            ctx.close()
+    return out
+
+
 def exact_bytes(workload: str):
     """(emit bytes / prim, SetupClusters bytes / prim, pipeline bytes / prim, source) of a PLOC-family workload from profiles/algorithmic_bytes.json, or None"""
     tab = _load_json("algorithmic_bytes.json") or {}
@@ -91,6 +154,7 @@ def main() -> None:
     ap.add_argument("--mesh", default="uniform", choices=["uniform", "bunny", "sponza"])
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="triangles of the mesh the CPU baseline is timed on (0 = skip); the whole 10 M mesh is ~25 s of single-thread work")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip the other configs' loops (N = 1) / the config-5-shaped exchange (N > 1)")
     args = ap.parse_args()
 
     import torch
@@ -167,23 +231,16 @@ def main() -> None:
 
     # Per-kernel HIP events are recorded on the launch stream INSIDE the timed region, for every 8th build (an event between two launches
     # costs a few microseconds of launch gap — one per launch of every build stretched a 1.42 ms build to 1.50): the kernels' average launch
-    # durations and the roofline come from those sampled builds of the timed region.
-    # The sampling phase is chosen so that the timed region's FIRST build is not a sampled one: the build right after the barrier's idle gap runs a few per cent
-    # slower (clocks), and with a short timed region (--steps 20: two or three samples) it would be a third of the kernels' averages.  The last `phase` of the W
-    # warm-up builds therefore run with the recorder already on (the library samples builds 0, 8, 16, ... after set_profiling); what they record is subtracted.
+    # durations and the roofline come from those sampled builds of the timed region — builds 0, 8, 16, ... of it, the first timed build included
+    # (round 3 shifted the phase so that the slightly slower first build after the barrier was never sampled; VERDICT / ADVICE r03: not any more).
     ctx.set_profiling(0)
     sample_every = 1 if args.steps < 16 else 8
-    phase = 0 if (sample_every == 1 or args.no_kernel_events) else min(args.warmup, sample_every // 2)
-    for _ in range(args.warmup - phase):
+    for _ in range(args.warmup):
         step()
     barrier()
     if not args.no_kernel_events:
         ctx.set_kernel_sampling(sample_every); ctx.set_profiling(2)
-    for _ in range(phase):
-        step()
-    barrier()
-    ktimes_warm = ctx.kernel_times() if phase else {}
-    n_sampled = sum(1 for i in range(phase, phase + args.steps) if i % sample_every == 0)
+    n_sampled = sum(1 for i in range(args.steps) if i % sample_every == 0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -195,8 +252,6 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()
-    if ktimes_warm:        # (the warm-up builds that ran with the recorder on)
-        ktimes = {k: (v[0] - ktimes_warm.get(k, (0.0, 0))[0], v[1] - ktimes_warm.get(k, (0.0, 0))[1]) for k, v in ktimes.items()}
     # all-gather of the root boxes: mean / max over the timed steps on this rank, device time incl. the 24-byte staging copy
     gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_events[-args.steps:]] if gather_events else []
     if gather and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
@@ -207,6 +262,30 @@ def main() -> None:
     stage = dict(builder.m_timer)
     sah = builder.sah_cost()
 
+    # ---- BASELINE.json config 5 at its own shape (N > 1 lines carry it next to the 10 M weak-scaling value): 2 M triangles per GPU, seed 100 + rank, offset (rank, 0, 0)
+    config5 = None
+    if gather and args.secondary:
+        n5 = 2_000_000
+        tris5 = pkg.meshgen.uniform(n5, 100 + rank, offset=(float(rank), 0.0, 0.0))
+        d5 = torch.from_numpy(tris5.view(np.uint8).reshape(-1)).cuda()
+        ctx.set_profiling(0)
+        d_keep, n_keep = d_tris, n
+        d_tris, n = d5, n5                                     # (step() builds whatever d_tris / n name)
+        for _ in range(5):
+            step()
+        barrier()
+        steps5 = 100
+        t0 = time.perf_counter()
+        for _ in range(steps5):
+            step()
+        barrier()
+        e5 = time.perf_counter() - t0
+        t5 = torch.tensor([e5], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        e5 = float(t5.item())
+        config5 = {"workload": f"uniform_{n5}_tris_hploc x {world} (seed 100 + rank, offset (rank, 0, 0))", "tris_per_gpu": n5, "steps": steps5,
+                   "ms_per_step": round(e5 / steps5 * 1e3, 4), "Mtris/s": round(n5 * world / (e5 / steps5) / 1e6, 1)}
+        d_tris, n = d_keep, n_keep
     if rank != 0:
         if gather:
             dist.destroy_process_group()
@@ -227,18 +306,21 @@ def main() -> None:
         per_prim, bytes_source = kernel_bytes_per_prim(name, args.algo, workload)
         alg_bytes = per_prim * n * (launches_per_build if name == "k_onesweep" else 1.0)
         achieved = alg_bytes / (per_build_ms * 1e-3) / 1e9 if per_build_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(f"{name}@{n}")
-            except Exception:
-                traffic = None
+        src_hash = kernel_source_hash()
+        pmc = _load_json("pmc_traffic.json") or {}
+        traffic = pmc.get(f"{name}@{n}")
+        rp = _load_json("rocprof_kernel_avg.json") or {}             # rocprofv3 --kernel-trace --stats averages of this command (tools/prof_round.sh)
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms_sum / launches, 4), "launches_per_step": launches_per_build,
                 "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_build, 1.0) if name == "k_onesweep" else alg_bytes,
-                "algorithmic_bytes_per_prim": round(per_prim, 3), "algorithmic_bytes_source": bytes_source}
+                "algorithmic_bytes_per_prim": round(per_prim, 3), "algorithmic_bytes_source": bytes_source,
+                # static inputs of this line (PMC traffic, SQ counters, rocprof average) were measured on the kernel sources with this hash; false = they predate HEAD's kernels
+                "profiles_match_kernel_sources": {"pmc_traffic": pmc.get("_kernel_source_hash") == src_hash, "kernel_source_hash": src_hash}}
+        rk = rp.get(f"{name}@{n}")
+        if rk:                                                      # the same fraction from the rocprofv3 kernel-trace average (all launches of the profiled run, warm-up included)
+            roof["frac_rocprof"] = round(alg_bytes / max(launches_per_build, 1.0) / (rk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if name == "k_onesweep" else round(alg_bytes / (rk["avg_us"] * 1e-6 * max(launches_per_build, 1.0)) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["rocprof_avg_us"] = rk["avg_us"]; roof["profiles_match_kernel_sources"]["rocprof"] = rp.get("_kernel_source_hash") == src_hash
         # the second bound: VALU / LDS pipe occupancy of this kernel from the committed SQ counters (profiles/issue_counters.json, written by
         # tools/prof_round.sh from a rocprofv3 --pmc pass of this command; recompute: insts x cycles_per_inst / (units x launch cycles))
         ic = (_load_json("issue_counters.json") or {}).get(f"{name}@{n}")
@@ -246,10 +328,16 @@ def main() -> None:
             cyc = ic["SQ_BUSY_CYCLES"] / ic["shader_engines"]                                    # launch length in shader cycles
             roof["issue"] = {"valu_busy_frac": round(ic["SQ_INSTS_VALU"] * ic["cycles_per_valu_inst"] / (ic["simds"] * cyc), 4),
                              "lds_busy_frac": round(ic["SQ_INSTS_LDS"] * ic["cycles_per_lds_inst"] / (ic["cus"] * cyc), 4),
-                             "waves_parked_frac": round(ic["SQ_WAIT_ANY"] / ic["SQ_WAVE_CYCLES"], 4), "source": "profiles/issue_counters.json"}
+                             "waves_parked_frac": round(ic["SQ_WAIT_ANY"] / ic["SQ_WAVE_CYCLES"], 4), "source": "profiles/issue_counters.json (priced estimate: instructions x measured cycles per instruction)"}
+            roof["profiles_match_kernel_sources"]["issue_counters"] = (_load_json("issue_counters.json") or {}).get("_kernel_source_hash") == src_hash
         if name in KERNEL_OWN_BYTES_PER_PRIM:     # the same kernel against the bytes it really has to move (work lists stay in LDS)
             own = KERNEL_OWN_BYTES_PER_PRIM[name] * n
             roof["own_bytes_per_launch"] = own; roof["own_frac"] = round(own / (per_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    # ---- the other configs on the record (N = 1): after the timed region, before the CPU baseline
+    secondary = None
+    if world == 1 and args.secondary:
+        del d_tris; torch.cuda.empty_cache()
+        secondary = run_secondary(pkg, torch, local)
     # ---- CPU baseline: reference's binned-SAH builder (oracle port), single thread, bounded sample of the same mesh
     cpu = None
     if args.cpu_sample > 0 and world == 1:                 # (rank 0 at N = 1 only: an N-GPU run does not hold its ranks for 23 s of CPU work)
@@ -270,12 +358,12 @@ def main() -> None:
                    "seed": "1+rank", "parallelism": f"scene-shard x{world}" + (" + allgather(root aabb)" if world > 1 else "")},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "kernel_ms_per_step": {k: round(v[0] / n_sampled, 4) for k, v in ktimes.items()},     # from the sampled builds of the timed region
-        "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds" + (f" ({n_sampled} builds, the first one at timed build {(-phase) % sample_every})" if sample_every > 1 else ""),
+        "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds, the first timed build included" + (f" ({n_sampled} builds)" if sample_every > 1 else ""),
         "sah_bvh2": round(sah, 4),
         "pipeline_roofline": {"algorithmic_bytes": pipeline_bytes, "source": ("exact: " + ex[3]) if ex else "SURVEY.md 8(d) constants (bvh_timings.bytes_algorithmic)",
                               "achieved_GBs": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "roofline": roof, "cpu_baseline": cpu, "mesh_gen_s": round(gen_s, 2),
+        "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "config5": config5, "mesh_gen_s": round(gen_s, 2),
         "allgather_us": ({"mean": round(float(np.mean(gather_us)), 2), "max": round(float(np.max(gather_us)), 2), "bytes_per_rank": 24} if gather_us else None),
     }
     print(json.dumps(out))

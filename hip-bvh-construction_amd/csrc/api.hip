@@ -71,7 +71,8 @@ struct bvh_ctx {
     int scene_slot = 0;               // which of the two scene extents the next build uses
     bool scene_ready = false;         // that extent holds Aabb::reset values (written by the previous build's Morton kernel); false: reset it explicitly
     uint32_t ploc_last_n = 0, ploc_last_iters = 0;   // size and iteration count of the last PLOC++ build (run_ploc aims its first batch of launches at it)
-    u32* h_pinned = nullptr;          // 16 + PLOC_STATE_WORDS pinned host words: small read-backs (root index, PLOC++ state) land here instead of in pageable caller memory
+    u32* h_pinned = nullptr;          // pinned, device-accessible host words: the small read-backs (root index, PLOC++ state, collapse level counts) land here as {v, ~v} pairs
+    u32* d_pinned = nullptr;          // the same words as the device addresses them
     float last_collapse_ms = 0.f;     // CollapseBvhTime of the last bvh_collapse4 (profiling on)
     uint32_t collapse_last_n = 0, collapse_last_levels = 0;   // levels the previous collapse of a tree of this size needed (first batch of launches)
     uint64_t collapse_last_key = 0;                           // ... of this KIND: {node layout, root index} — an LBVH and a PLOC tree of one size have different level widths
@@ -103,21 +104,23 @@ void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_sk
 inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return -(int)_e; } while (0)
 
-// The per-build read-backs (single-pass LBVH root index, PLOC++ iteration state, the collapse's level counts) are small copies into pinned host words.
-// The host learns that they have landed by polling the words themselves: the caller stores `sentinel` (a value the device never writes) into EVERY word it is
-// going to read before enqueuing the copies, and wait_readback returns once NONE of them holds the sentinel any more — hipStreamSynchronize notices the end of
-// the stream ~6 us later than a poll of the words does (tools/probes/sync_latency.hip: 343.6 vs 337.7 us for eight launches + the copy), 4 % of a
-// 262 144-triangle LBVH build.  Every word is validated on its own (an aligned 4-byte word lands atomically; acquire loads, so nothing read afterwards can be
-// hoisted above the poll): no assumption about the order in which two copies, or the bytes of one copy, become visible to the host (round 3 polled the LAST
-// word only and trusted DMA ordering for the others — ADVICE r03).  The stream is in order, so everything enqueued before the copies is complete when the words
-// have changed.  The poll is bounded: after ~4 M rounds (some tens of milliseconds: a build that long does not care) it falls back to
-// hipStreamSynchronize, which also surfaces an error of the stream.
+// The per-build read-backs (single-pass LBVH root index, PLOC++ iteration state, the collapse's level counts) are a handful of words.  They come back as PAIRS
+// {v, ~v} written by a one-workgroup kernel straight into pinned, device-accessible host words (misc.hip launch_readback); the caller arms every pair with
+// {sentinel, sentinel} — an inconsistent pair — and wait_readback polls until EVERY pair reads {v, ~v}: hipStreamSynchronize notices the end of the stream ~6 us later
+// than a poll of the words does (tools/probes/sync_latency.hip), 4 % of a 262 144-triangle LBVH build.  A consistent pair proves that every byte of both words is final:
+// no assumption about the order or the granularity in which a copy becomes visible to the host (round 3 polled the last word of a hipMemcpyAsync for "not the
+// sentinel" — ADVICE r03 —, and round 4 caught that copy landing byte by byte: see misc.hip).  Acquire loads: nothing read afterwards can be hoisted above the poll.  The
+// stream is in order, so everything enqueued before the read-back kernel is complete when the pairs are.  Bounded: after ~4 M rounds it falls back to hipStreamSynchronize,
+// which also surfaces an error of the stream.
 #ifndef BVH_POLL_READBACK
 #define BVH_POLL_READBACK 1
 #endif
-static int wait_readback(hipStream_t s, const u32* words, u32 count, u32 sentinel) {
+static int wait_readback(hipStream_t s, const u32* pairs, u32 count) {
     auto all_landed = [&]() -> bool {
-        for (u32 i = 0; i < count; ++i) if (__atomic_load_n(words + i, __ATOMIC_ACQUIRE) == sentinel) return false;
+        for (u32 i = 0; i < count; ++i) {
+            const u32 v = __atomic_load_n(pairs + 2 * i, __ATOMIC_ACQUIRE), w = __atomic_load_n(pairs + 2 * i + 1, __ATOMIC_ACQUIRE);
+            if (w != ~v) return false;
+        }
         return true;
     };
 #if BVH_POLL_READBACK
@@ -131,10 +134,12 @@ static int wait_readback(hipStream_t s, const u32* words, u32 count, u32 sentine
     HIP_TRY(hipStreamSynchronize(s));
     return all_landed() ? 0 : BVH_E_INTERNAL;
 }
-static inline void arm_readback(u32* words, u32 count, u32 sentinel) {
-    for (u32 i = 0; i < count; ++i) __atomic_store_n(words + i, sentinel, __ATOMIC_RELAXED);
+static inline void arm_readback(u32* pairs, u32 count) {
+    for (u32 i = 0; i < 2 * count; ++i) __atomic_store_n(pairs + i, 0xFFFFFFFFu, __ATOMIC_RELAXED);      // {S, S}: never a consistent pair
     __atomic_thread_fence(__ATOMIC_RELEASE);
 }
+// enqueue the read-back of na words at d_a and nb words at d_b behind everything on the stream and wait for it; the values are then pairs[2 i]
+static int read_back(bvh_ctx* c, const u32* d_a, u32 na, const u32* d_b, u32 nb, u32* pairs);
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -219,6 +224,13 @@ struct Bind { int prev = -1; bool ok = true;
     explicit Bind(int dev) { ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess); }
     ~Bind() { int cur; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) hipSetDevice(prev); } };
 
+static int read_back(bvh_ctx* c, const u32* d_a, u32 na, const u32* d_b, u32 nb, u32* pairs) {
+    arm_readback(pairs, na + nb);
+    launch_readback(c->stream, d_a, na, d_b, nb, c->d_pinned + (pairs - c->h_pinned));
+    HIP_TRY(hipGetLastError());
+    return wait_readback(c->stream, pairs, na + nb);
+}
+
 // PLOC++ iteration driver: batches of device-side iterations, one small read-back per batch (src/PLOC++Bvh.cpp:132-152
 // reads back after EVERY iteration).
 int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const u32* d_svals, const PlocScratch& sc, uint32_t* iterations_out) {
@@ -246,13 +258,10 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
         }
         ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh);
         fresh = false;
-        // two words come back: the iterations done so far and the cluster count after this batch; the host polls BOTH (wait_readback); counts and
-        // iteration numbers are < 2^30, the sentinel is neither
-        u32* const h_iters = c->h_pinned + 1; u32* const h_count = c->h_pinned + 2;      // (adjacent: one poll covers both)
-        arm_readback(h_iters, 2, 0xFFFFFFFFu);
-        HIP_TRY(hipMemcpyAsync(h_iters, sc.state + 2 * PLOC_MAX_ITERS + 1, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h_count, sc.state + first + batch, 4, hipMemcpyDeviceToHost, c->stream));
-        { const int wr = wait_readback(c->stream, h_iters, 2, 0xFFFFFFFFu); if (wr) return wr; }
+        // two words come back: the iterations done so far and the cluster count after this batch (pairs at pinned words 4..7)
+        u32* const rb = c->h_pinned + 4;
+        { const int wr = read_back(c, sc.state + 2 * PLOC_MAX_ITERS + 1, 1, sc.state + first + batch, 1, rb); if (wr) return wr; }
+        const u32* const h_iters = rb; const u32* const h_count = rb + 2;
         const u32 count = *h_count;
         if (count <= 1) {
             c->ploc_last_n = n; c->ploc_last_iters = *h_iters;
@@ -348,7 +357,8 @@ int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
     else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { c->stream = nullptr; bvh_ctx_destroy(c); return -(int)e; } c->own_stream = true; }
     // (a failure from here on goes through bvh_ctx_destroy, which releases whatever exists: stream, events, pinned words)
     for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { e = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
-    { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocDefault); if (r != hipSuccess) { c->h_pinned = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
+    { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocMapped); if (r != hipSuccess) { c->h_pinned = nullptr; bvh_ctx_destroy(c); return -(int)r; }
+      void* dp = nullptr; r = hipHostGetDevicePointer(&dp, c->h_pinned, 0); if (r != hipSuccess) { bvh_ctx_destroy(c); return -(int)r; } c->d_pinned = static_cast<u32*>(dp); }
     *out = c;
     return 0;
 }
@@ -477,7 +487,7 @@ int bvh_emit_lbvh_single(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d
     r = begin_emit(c); if (r) return r;
     launch_lbvh_single(c->stream, d_prim_aabbs, d_sorted_keys, 32, d_sorted_vals, n, d_nodes, c->hploc.dep, c->small, c->ploc.list0, c->lbvh_queue_capacity, c->hploc.queue_count, false, (int)c->options[BVH_OPT_LBVH_SCHEDULER]);
     r = end_emit(c); if (r) return r;
-    if (root_out) { arm_readback(c->h_pinned, 1, 0xFFFFFFFFu); HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, c->stream)); r = wait_readback(c->stream, c->h_pinned, 1, 0xFFFFFFFFu); if (r) return r; *root_out = c->h_pinned[0]; }
+    if (root_out) { r = read_back(c, c->small, 1, nullptr, 0, c->h_pinned); if (r) return r; *root_out = c->h_pinned[0]; }
     return 0;
 }
 
@@ -574,10 +584,9 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (install.on) c->recorder.mark(s, nullptr);
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (algo == BVH_LBVH_SINGLEPASS) {   // m_rootNodeIdx read-back (src/SinglePassLbvh.cpp:131)
-        arm_readback(c->h_pinned, 1, 0xFFFFFFFFu);                                         // (no node has this index: n < 2^30)
-        HIP_TRY(hipMemcpyAsync(c->h_pinned, c->small, 4, hipMemcpyDeviceToHost, s));      // (pinned: a copy into pageable memory goes through a staging buffer)
-        r = wait_readback(s, c->h_pinned, 1, 0xFFFFFFFFu); if (r) return r;
+        r = read_back(c, c->small, 1, nullptr, 0, c->h_pinned); if (r) return r;           // {root, ~root} into pinned words 0..1
         out->root = c->h_pinned[0];
+        if (out->root >= 2u * n - 1u) return BVH_E_INTERNAL;                               // (an index that consumers turn into an address)
     }
     out->d_nodes = c->nodes; out->d_prim_aabbs = c->boxes; out->d_scene_extent = scene;
     out->d_sorted_keys = c->skeys; out->d_sorted_vals = c->svals;
@@ -646,8 +655,8 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
     collapse_begin(s, taskq, state, in->root, true);
     // a batch's level counts come back into pinned words (a copy into pageable memory goes through a staging buffer and blocks); the host polls every one
     // of them (counts are < 2^31: the sentinel is not a count) instead of synchronising the stream — see wait_readback
-    u32* const host = c->h_pinned + 16;
-    static_assert(COLLAPSE_MAX_BATCH <= PLOC_STATE_WORDS, "pinned read-back words");
+    u32* const host_pairs = c->h_pinned + 16;
+    static_assert(2 * COLLAPSE_MAX_BATCH <= PLOC_STATE_WORDS, "pinned read-back words");
     // wide levels ~ half the BVH2 depth: a first batch sized for a balanced tree — or one above what the previous collapse of a tree of this size needed
     // (animation frames, the benchmark loop: a level launched after the end costs ~3 us) —, then batches of 16 until a level creates nothing
     int batch = 10; for (uint32_t m = n; m > 1u; m >>= 1) batch += 1;
@@ -661,9 +670,9 @@ int bvh_collapse4(bvh_ctx* c, const bvh_result* in, void* d_bvh4, void* d_primno
         collapse_enqueue(s, in->d_nodes, in->d_leaves, d_bvh4, d_primnodes, taskq, state, base_begin, base_len, batch, n, (int)in->layout,
                          known ? c->collapse_last_len : nullptr);
         HIP_TRY(hipGetLastError());
-        arm_readback(host, (u32)batch, 0xFFFFFFFFu);
-        HIP_TRY(hipMemcpyAsync(host, state, (size_t)batch * sizeof(u32), hipMemcpyDeviceToHost, s));
-        r = wait_readback(s, host, (u32)batch, 0xFFFFFFFFu); if (r) return r;
+        r = read_back(c, state, (u32)batch, nullptr, 0, host_pairs); if (r) return r;
+        u32 host[COLLAPSE_MAX_BATCH];
+        for (int l = 0; l < batch; ++l) host[l] = host_pairs[2 * l];
         u32 len = base_len, allocated = base_begin + base_len;       // ids handed out so far
         u32 lens[COLLAPSE_MAX_BATCH + 1]; lens[0] = base_len;
         for (int l = 0; l < batch; ++l) { if (len) ++levels; len = host[l]; allocated += len; lens[l + 1] = len; }
@@ -779,8 +788,9 @@ int bvh_dev_download(bvh_ctx* c, void* h_dst, const void* d_src, uint64_t bytes)
     if (!c) return BVH_E_INVALID_ARG; Bind b(c->device);
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream)); return herr(hipStreamSynchronize(c->stream)); }
 
-int bvh_dev_copy(bvh_ctx* c, void* d_dst, const void* d_src, uint64_t bytes) {   // asynchronous, ordered on the ctx's stream
-    if (!c) return BVH_E_INVALID_ARG; Bind b(c->device);
-    return herr(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream)); }
+int bvh_dev_copy(bvh_ctx* c, void* d_dst, const void* d_src, uint64_t bytes) {   // asynchronous, ordered on the ctx's stream; a kernel, not a runtime copy (misc.hip)
+    if (!c || (bytes && (!d_dst || !d_src))) return BVH_E_INVALID_ARG; Bind b(c->device);
+    launch_copy_bytes(c->stream, d_dst, d_src, (size_t)bytes);
+    return herr(hipGetLastError()); }
 
 } // extern "C"

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <atomic>
+#include <cstdio>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -140,6 +141,13 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
             bvh_result r; bvh_timings t;
             int rc2 = bvh_build(c, algo, h_tris[m], n_tris[m], 0, &r, &t); if (rc2) return fail(rc2);
             if (rep->build_ms) rep->build_ms[m] = t.ms_total;
+            if (r.root >= tree_nodes(algo, n_tris[m]) || !r.d_nodes) {
+#ifdef BATCH_DEBUG
+                uint32_t again = 0; (void)bvh_ctx_synchronize(c); (void)bvh_dev_download(c, &again, (const char*)r.d_sorted_keys, 4);
+                fprintf(stderr, "batch: mesh %d lane %d n %u root %u (0x%x) key0 %u\n", m, l, n_tris[m], r.root, r.root, again);
+#endif
+                return fail(BVH_E_INTERNAL);      // (never trust an index that is about to become an address)
+            }
             // root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
             rc2 = bvh_dev_copy(c, b->d_send[d] + 6 * k, (const char*)r.d_nodes + 32 * (size_t)r.root + 8, 24); if (rc2) return fail(rc2);
             if (rep->checksums) { rc2 = bvh_checksum(c, &r, &rep->checksums[m]); if (rc2) return fail(rc2); }

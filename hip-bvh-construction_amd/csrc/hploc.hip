@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 // drain, no atomic, and only the sibling's records to load.  Otherwise the usual protocol runs unchanged.  (Whenever a node's continuation
 // passes to another wave it is through the usual protocol, whose drain also covers the node stores made since.)
 #ifdef ABL_EXT_TRACE     // measurement build: the tasks of more than n / 4096 leaves leave {start, end (100 MHz clock), range, hand-over taken} in the unused tail of the queue buffer
-__device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap, u64 t0, u32 L, u32 R, u32 ni, u32 kind, u32 nrounds, u64 t_loaded = 0, u64 t_rounds = 0) {
+__device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap, u64 t0, u32 L, u32 R, u32 ni, u32 kind, u32 nrounds, u64 t_loaded = 0, u64 t_rounds = 0, u64 t_done = 0) {
     if ((R - L + 1u) <= (ni + 1u) / 4096u) return;
 #ifdef EXT_TRACE_NOP
     return;
@@ -1013,7 +1013,8 @@ __device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap,
     const u32 at = atomicAdd(trace_count, 1u);
     // e[3]: kind | rounds << 8 | (ticks from the pass's start to "work list loaded") << 16 | (... to "rounds done") << 32 (100 MHz ticks, 16 bits each)
     if (at < cap) { u64* e = trace + (size_t)at * 4u; e[0] = t0; e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = (u64)L | ((u64)R << 32);
-                    e[3] = (u64)kind | ((u64)nrounds << 8) | (((t_loaded - t0) & 0xFFFFull) << 16) | (((t_rounds - t0) & 0xFFFFull) << 32); }
+                    // (bits 48..63: ... to "hand-over done", stamped BEFORE this function's own atomic: e[1] includes the trace's round trip, this does not)
+                    e[3] = (u64)kind | ((u64)nrounds << 8) | (((t_loaded - t0) & 0xFFFFull) << 16) | (((t_rounds - t0) & 0xFFFFull) << 32) | (((t_done - t0) & 0xFFFFull) << 48); }
 }
 #define EXT_TRACE_ARGS , u64* trace = nullptr, u32* trace_count = nullptr, u32 trace_cap = 0u
 #define EXT_TRACE_PASS , trace, trace_count, trace_cap
@@ -1128,7 +1129,9 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     cw.id = w.id; cw.rep = w.rep; cw.b = w.b;
 #ifdef ABL_EXT_TRACE
 #if !defined(EXT_TRACE_NOHOOK)
-    if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds, tr1, tr2);
+    asm volatile("" : "+v"(L), "+v"(R));
+    const u64 tr3 = __builtin_amdgcn_s_memrealtime();
+    if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds, tr1, tr2, tr3);
 #else
     if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds);
 #endif

@@ -155,6 +155,9 @@ void launch_trace_kind(hipStream_t s, int kind, const void* d_rays, const void* 
 
 // ---- helpers (misc.hip)
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out);
+void launch_copy_bytes(hipStream_t s, void* d_dst, const void* d_src, size_t bytes);
+// na words at d_a, then nb words at d_b (either may be empty), written as pairs {v, ~v} into 2 (na + nb) device-accessible pinned host words
+void launch_readback(hipStream_t s, const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t* pinned_pairs);      // device-to-device copy as a kernel (no runtime copy path)
 void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t root, uint32_t n, int layout, double* d_out /*[1], zeroed inside*/);
 
 void launch_bvh4_cost(hipStream_t s, const void* d_wide, uint32_t n_wide, const void* d_prims, const void* d_prim_boxes, uint32_t n, double* d_out /*[1], zeroed inside*/);

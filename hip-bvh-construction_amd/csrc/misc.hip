@@ -132,6 +132,38 @@ void launch_checksum(hipStream_t s, const void* d_nodes, uint32_t n_nodes, const
     hipLaunchKernelGGL(k_checksum, dim3(blocks < 2048u ? blocks : 2048u), dim3(256), 0, s, (const u32*)d_nodes, n_nodes, (const u32*)d_leaves, d_leaves ? n_leaves : 0u, root, (unsigned long long*)d_out);
 }
 
+// Small read-backs (single-pass LBVH root index, PLOC++ iteration state, the collapse's level counts): one workgroup writes every word as a PAIR {v, ~v} straight into
+// the context's pinned host words (host memory is device-accessible), and the host polls until every pair is consistent (api.hip wait_readback).  Round 3 copied the
+// words with a 4-byte hipMemcpyAsync and polled for "not the sentinel any more": that copy is performed BYTE-WISE — under the batched builder's three concurrent streams
+// the host read 0xff000972 and 0xffff09e9 (two and three bytes of a root index landed, the rest still the sentinel) and turned them into addresses (round 4,
+// tools/probes/batch_stress.py).  A pair can only be consistent when every byte of both words is final.
+__global__ __launch_bounds__(64) void k_readback(const u32* __restrict__ a, u32 na, const u32* __restrict__ b, u32 nb, u32* out) {
+    for (u32 i = threadIdx.x; i < na + nb; i += 64) {
+        const u32 v = i < na ? a[i] : b[i - na];
+        __hip_atomic_store(out + 2 * i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out + 2 * i + 1, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void launch_readback(hipStream_t s, const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t* pinned_pairs) {
+    hipLaunchKernelGGL(k_readback, dim3(1), dim3(64), 0, s, d_a, na, d_b, nb, pinned_pairs);
+}
+
+// device-to-device copy as a kernel (bvh_dev_copy).  hipMemcpyAsync(DeviceToDevice) of a few bytes takes a host-side path in the runtime (a CPU memcpy through the
+// BAR mapping) that crashed when several host threads of the batched builder copied while another thread re-allocated its arena (round 4: SIGSEGV inside
+// hipMemcpyAsync under tools/probes/batch_stress.py); a kernel only ever touches the memory from the device, on the caller's stream.
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy(T* __restrict__ dst, const T* __restrict__ src, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_bytes(hipStream_t s, void* d_dst, const void* d_src, size_t bytes) {
+    if (!bytes) return;
+    const uintptr_t a = (uintptr_t)d_dst | (uintptr_t)d_src | (uintptr_t)bytes;
+    auto grid = [](size_t count) { const size_t b = (count + 255) / 256; return dim3((unsigned)(b < 4096 ? b : 4096)); };
+    if ((a & 15u) == 0) hipLaunchKernelGGL(k_copy<uint4>, grid(bytes / 16), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)d_src, bytes / 16);
+    else if ((a & 3u) == 0) hipLaunchKernelGGL(k_copy<u32>, grid(bytes / 4), dim3(256), 0, s, (u32*)d_dst, (const u32*)d_src, bytes / 4);
+    else hipLaunchKernelGGL(k_copy<unsigned char>, grid(bytes), dim3(256), 0, s, (unsigned char*)d_dst, (const unsigned char*)d_src, bytes);
+}
+
 void launch_to_lbvh_layout(hipStream_t s, const void* d_nodes, const void* d_leaves, uint32_t n, void* d_out) {
     hipLaunchKernelGGL(k_to_lbvh_layout, dim3((n + 255) / 256), dim3(256), 0, s, (const bvh2_node*)d_nodes, (const bvh_primref*)d_leaves, n, (bvh2_node*)d_out);
 }

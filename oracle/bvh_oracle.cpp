@@ -544,6 +544,8 @@ void orc_ploc(const void* boxes, u32 n, const u32* svals, void* nodes_out, void*
 // Compaction is modelled as "valid lanes write to their rank, slot[count] = INVALID" — the outcome of :183-185 when the
 // highest lane's store wins.
 }  // extern "C"
+// optional per-task trace of the merge tasks (tools/model_hploc.py replays it): {L, R, split, rounds, clusters loaded} per plocMerge call, in execution order
+static std::vector<u32>* g_hploc_trace = nullptr;
 template <typename K>
 static void hploc_impl(const void* boxes, u32 n, const K* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) {
     const Box* pb = (const Box*)boxes; Node2* nd = (Node2*)nodes_out; Leaf* lf = (Leaf*)leaves_out;
@@ -579,11 +581,12 @@ static void hploc_impl(const void* boxes, u32 n, const K* skeys, const u32* sval
         const u32 nr = load(split, R + 1, nl);
         u32 cnt = nl + nr;
         st.cluster_loads += cnt;
+        const u32 cnt0 = cnt; u32 task_rounds = 0;
         const u32 threshold = final_ ? 1 : HALF;
         for (int s = 0; s < W; ++s)                            // :242-246
             if (slot[s] != INV) sb[s] = slot[s] >= ni ? lf[slot[s] - ni].b : nd[slot[s]].b;
         while (cnt > threshold) {
-            st.nn_rounds++;
+            st.nn_rounds++; ++task_rounds;
             for (int s = 0; s < W; ++s) nn[s] = ~0ull;         // findNearestNeighbours :83-117
             for (u32 s = 0; s < cnt; ++s)
                 for (int r = 1; r <= RAD; ++r) {
@@ -613,6 +616,7 @@ static void hploc_impl(const void* boxes, u32 n, const K* skeys, const u32* sval
         }
         for (u32 s = 0; s < nl + nr; ++s) idx[L + s] = slot[s];   // storeIndices :208-218
         st.cluster_stores += nl + nr;
+        if (g_hploc_trace) { const u32 rec[5] = { L, R, split, task_rounds, cnt0 }; g_hploc_trace->insert(g_hploc_trace->end(), rec, rec + 5); }
     };
     for (u32 g = 0; g < n; ++g) {                              // HPloc :257-315, one walker at a time
         u32 L = g, R = g;
@@ -637,6 +641,16 @@ static void hploc_impl(const void* boxes, u32 n, const K* skeys, const u32* sval
 extern "C" {
 void orc_hploc(const void* boxes, u32 n, const u32* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) { hploc_impl<u32>(boxes, n, skeys, svals, nodes_out, leaves_out, stats_out); }
 void orc_hploc64(const void* boxes, u32 n, const u64* skeys, const u32* svals, void* nodes_out, void* leaves_out, void* stats_out) { hploc_impl<u64>(boxes, n, skeys, svals, nodes_out, leaves_out, stats_out); }
+// the merge tasks of an HPLOC build: tasks_out = u32[5 * cap] {L, R, split, rounds, clusters loaded}; returns the number of tasks (<= cap are written)
+u32 orc_hploc_tasks(const void* boxes, u32 n, const u32* skeys, const u32* svals, u32* tasks_out, u32 cap) {
+    std::vector<Node2> nodes(n > 1 ? n - 1 : 1); std::vector<Leaf> leaves(n);
+    std::vector<u32> tr; g_hploc_trace = &tr;
+    hploc_impl<u32>(boxes, n, skeys, svals, nodes.data(), leaves.data(), nullptr);
+    g_hploc_trace = nullptr;
+    const u32 cnt = (u32)(tr.size() / 5);
+    std::memcpy(tasks_out, tr.data(), sizeof(u32) * 5 * std::min(cnt, cap));
+    return cnt;
+}
 
 // ---- SAH cost, BVH2.  Formula of Utility::calculateLbvhCost (src/Utility.cpp:317-349): 1 + sum over internal nodes of both
 // child areas / rootArea + sum over leaves of area / rootArea.  Returned in f64 (order independent to ~1e-12) and, through

@@ -176,6 +176,17 @@ def hploc(boxes, skeys, svals):
     return nodes, leaves, {k: int(st[k][0]) for k in STATS.names}
 
 
+def hploc_tasks(boxes, skeys, svals) -> np.ndarray:
+    """the merge tasks of the HPLOC build of these sorted leaves: (T, 5) uint32 {L, R, split, rounds, clusters loaded} in the oracle's execution order"""
+    n = boxes.shape[0]
+    L = lib(); L.orc_hploc_tasks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]; L.orc_hploc_tasks.restype = C.c_uint32
+    cap = n // 8 + 16
+    out = np.zeros((cap, 5), dtype=np.uint32)
+    cnt = L.orc_hploc_tasks(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, out.ctypes.data, cap)
+    assert cnt <= cap
+    return out[:cnt]
+
+
 def build_tree(algo: int, tris: np.ndarray, morton_bits: int = 30) -> dict:
     """Whole pipeline on the CPU.  algo: 0 two-pass, 1 single-pass, 2 PLOC++, 3 HPLOC."""
     fe = front_end(tris, morton_bits)

@@ -29,6 +29,7 @@ L = (ev[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64); R = (ev[:, 2] >> np.uin
 kind = (ev[:, 3] & np.uint64(0xFF)).astype(int); rounds = ((ev[:, 3] >> np.uint64(8)) & np.uint64(0xFF)).astype(int)
 d_load = ((ev[:, 3] >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64) / 100.0       # us from the pass's start until the work list is in registers
 d_rnd = ((ev[:, 3] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64) / 100.0        # ... until the rounds are done
+d_done = ((ev[:, 3] >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.int64) / 100.0       # ... until the hand-over is done (before the trace's own atomic)
 size = R - L + 1
 print(f"n={n}: {len(ev)} traced tasks; first start {t0.min():.1f} us, last end {t1.max():.1f} us")
 names = {1: "fast(late)", 2: "slow-continue", 3: "stop", 4: "fast(early)"}
@@ -56,5 +57,5 @@ print("critical chain, bottom-up: size, start, end, rounds, hand-over kind; then
 prev_end = None
 for c in reversed(chain):
     gap = (t0[c] - prev_end) if prev_end is not None else 0.0
-    print(f"  {size[c]:9d}  {t0[c]:7.1f} -> {t1[c]:7.1f}  ({t1[c]-t0[c]:5.2f} us, {rounds[c]} rounds)  {names.get(kind[c], kind[c])}   gap before {gap:5.2f}  list load {d_load[c]:5.2f}  rounds {d_rnd[c]-d_load[c]:5.2f}  hand-over {t1[c]-t0[c]-d_rnd[c]:5.2f}")
+    print(f"  {size[c]:9d}  {t0[c]:7.1f} -> {t1[c]:7.1f}  ({t1[c]-t0[c]:5.2f} us, {rounds[c]} rounds)  {names.get(kind[c], kind[c])}   gap before {gap:5.2f}  list load {d_load[c]:5.2f}  rounds {d_rnd[c]-d_load[c]:5.2f}  hand-over {d_done[c]-d_rnd[c]:5.2f}  (the trace's own atomic {t1[c]-t0[c]-d_done[c]:5.2f})")
     prev_end = t1[c]

@@ -30,9 +30,15 @@ def main():
                                           "launches_averaged": cnt, "source": "rocprofv3 --pmc " + " ".join(WANT) + " -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events"})
         e[counter] = avg
     for k, e in out.items():
+        if k.startswith("_"):
+            continue
         cyc = e["SQ_BUSY_CYCLES"] / 32
         print(k, "valu_busy %.3f  lds_busy %.3f  parked %.3f" % (e["SQ_INSTS_VALU"] * e["cycles_per_valu_inst"] / (1024 * cyc), e["SQ_INSTS_LDS"] * e["cycles_per_lds_inst"] / (256 * cyc), e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]))
     if len(sys.argv) > 3:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _srchash import kernel_source_hash
+        out["_kernel_source_hash"] = kernel_source_hash()
         json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 

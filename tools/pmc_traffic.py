@@ -33,6 +33,10 @@ def main():
         out[f"{k}@{n}"] = int(traffic)
         print(f"| {k} | {fc / builds:.1f} | {fk / builds:.0f} | {wk / builds:.0f} | {traffic:.4g} | {traffic / n:.1f} |")
     if len(sys.argv) > 5:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _srchash import kernel_source_hash
+        out["_kernel_source_hash"] = kernel_source_hash()
         json.dump(out, open(sys.argv[5], "w"), indent=1, sort_keys=True)
 
 
