@@ -1170,11 +1170,15 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, u32* q_count, u32 q_cap, u32 n) {
     __shared__ u64 s_nn[256 / WAVE][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1);
+#if HPX_LDS_LIST          // (A/B switch, off: the per-wave work lists of that variant — 8 KB of LDS the default kernel does not reserve)
     __shared__ u64 s_lir[256 / WAVE][WAVE];
     __shared__ float2 s_lb[3][256 / WAVE][WAVE + 1];
-    const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x / WAVE;
     const WaveList wl{ s_lir[wv], s_lb[0][wv], s_lb[1][wv], s_lb[2][wv] };
+#else
+    const WaveList wl{ nullptr, nullptr, nullptr, nullptr };
+#endif
     const u32 nwaves = gridDim.x * (256 / WAVE);
     const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
     const u32 sub = wid % HPQ_SUB;                                       // (nwaves is a multiple of HPQ_SUB)

@@ -148,40 +148,11 @@ __device__ __forceinline__ void ploc_tail_wave(PlocLds& s, u32 c, bvh2_node* __r
     }
 }
 
-// counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
-// FIRST: the build's first iteration reads the clusters straight from the sorted values and the primitive boxes and writes the
-// PrimRef leaves on the way — SetupClusters (:39-55) fused: the initial cluster list (32 B written + 32 B read per primitive) never exists.
-#ifndef PLOC_OCC
-#define PLOC_OCC 5
-#endif
-template <int PL_BLOCK, bool FIRST>
-__global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
-                                                        bvh2_node* __restrict__ nodes,
-                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
-                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
-    constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
-    __shared__ PlocLds s;
-    const u32 C = counts[0];
-    if (C <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = C; return; }
-    const int tid = threadIdx.x;
-    // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
-    auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
-        if (FIRST) {
-            const u32 prim = svals[g];
-            b = box_gather(boxes + prim); id = (u32)g + ni;
-            if (own) {
-                float* f = reinterpret_cast<float*>(leaves + g);
-                reinterpret_cast<u32*>(f)[0] = prim;
-                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-            }
-        } else entry_load(list_in, g, id, b);
-    };
-
-    // (lo, hi: first valid span entry, one past the last; the tail below runs it on the whole list, lo = 0)
-    auto nn_pairs = [&](const int lo, const int hi) {
-        // nearest neighbours for list positions [o-8, o+1032): everything a chunk cluster or its neighbour needs (:252-270).  As the reference does it:
-        // every pair (s, s + r), r = 1..8, is evaluated ONCE and minimised as {area bits, other position} into both ends' words (LDS atomics).  A
-        // 16-lane DPP row holds 32 consecutive span entries, two per lane, and evaluates the pairs of its first 24 (common.hpp, row_shl): the
+// Nearest neighbours of the span entries [lo, hi) (lo: first valid entry, hi: one past the last): everything a chunk cluster or its neighbour needs (:252-270).  As the
+// reference does it: every pair (s, s + r), r = 1..8, is evaluated ONCE and minimised as {area bits, other position} into both ends' words (LDS atomics).
+template <int PL_BLOCK>
+__device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int lo, const int hi) {
+        // A 16-lane DPP row holds 32 consecutive span entries, two per lane, and evaluates the pairs of its first 24 (common.hpp, row_shl): the
         // boxes are read from LDS once (round 1 read the 16 neighbours of every entry: 192 LDS reads per cluster, the limiter of the mid-size iterations).
         {
             constexpr int ROWS = PL_BLOCK / 16, TILES = (PL_HALO + PLOC_CHUNK + PL_RADIUS + 23) / 24;     // pairs with s in [0, 1048)
@@ -211,7 +182,38 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
                 cand(row_shl<3>(bB), row_shl<4>(bA), 7);   cand(row_shl<4>(bA), row_shl<4>(bB), 8);
             }
         }
+}
+
+// counts[k] = cluster count at the start of iteration k; tickets[k] = chunk ticket of iteration k; status: u64 per chunk
+// FIRST: the build's first iteration reads the clusters straight from the sorted values and the primitive boxes and writes the
+// PrimRef leaves on the way — SetupClusters (:39-55) fused: the initial cluster list (32 B written + 32 B read per primitive) never exists.
+#ifndef PLOC_OCC
+#define PLOC_OCC 5
+#endif
+template <int PL_BLOCK, bool FIRST>
+__global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
+                                                        bvh2_node* __restrict__ nodes,
+                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
+                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
+    constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
+    __shared__ PlocLds s;
+    const u32 C = counts[0];
+    if (C <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = C; return; }
+    const int tid = threadIdx.x;
+    // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
+    auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
+        if (FIRST) {
+            const u32 prim = svals[g];
+            b = box_gather(boxes + prim); id = (u32)g + ni;
+            if (own) {
+                float* f = reinterpret_cast<float*>(leaves + g);
+                reinterpret_cast<u32*>(f)[0] = prim;
+                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+            }
+        } else entry_load(list_in, g, id, b);
     };
+
+    auto nn_pairs = [&](const int lo, const int hi) { nn_pairs_fn<PL_BLOCK>(s, tid, lo, hi); };
     if (C < (u32)PLOC_CHUNK) {
         // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
         if (blockIdx.x != 0) return;
@@ -382,6 +384,154 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
 #endif
 }
 
+// =====================================================================================================================
+// Resident iterations (round 4): for lists of at most PLOC_RESIDENT_MAX_WG chunks — config 4's Sponza-class 262 144 is exactly 256 — ONE
+// cooperative launch of one 1024-thread workgroup per chunk runs the first iterations with every workgroup's part of the list RESIDENT IN LDS.  A launch-per-
+// iteration pass re-reads its 32-byte entries through L2, walks a look-back chain and writes the compacted list back, every time (~11 us per iteration at 262 144,
+// of which the work is ~3); here an iteration is: nearest neighbours on the LDS span, merge decisions, block scan, ONE global exchange, node stores, compaction in LDS.
+// The exchange: a workgroup publishes {epoch, merges, kept} in one 64-bit word and the first / last 16 entries of its NEW list part (the halos its neighbours need for
+// the next iteration; a cluster merged in this very iteration is published as its local merge rank — the reader resolves the node index from the prefix it computes
+// anyway), then reads everybody's word: prefix of the merges before it (node index = C - 2 - rank in list order: the same deterministic numbering as k_ploc_iter), the new
+// cluster count, the smallest part.  Parts shrink ~20 % per iteration and are NOT rebalanced: the launch ends when the smallest part falls below the halo width (16)
+// or the list below two chunks, writes the list out in order and the ordinary per-iteration launches finish the build (~10 of ~30 iterations at 262 144).
+// Co-residency is guaranteed by the cooperative launch (which fails — and the host falls back to the per-iteration path — when the device cannot hold the grid).
+// The chunking itself does not matter for the result: with a halo of 2 x radius every cluster sees the same 16 neighbours whatever the partition (:232-270).
+// =====================================================================================================================
+struct PlocXchg {                          // one per workgroup and parity
+    u64 word;                              // {epoch : 32 | merges : 16 | kept : 16}
+    u64 pad;
+    float4 first[PL_HALO][2];              // entries {idcode, lx, ly, lz} {hx, hy, hz, -}; idcode: node / leaf id, or 0x80000000 | local merge rank of this iteration
+    float4 last[PL_HALO][2];
+};
+static_assert(sizeof(PlocXchg) == 16 + 2 * PL_HALO * 32, "exchange record");
+size_t ploc_xchg_bytes() { return 2 * (size_t)PLOC_RESIDENT_MAX_WG * sizeof(PlocXchg); }
+
+__device__ __forceinline__ void xchg_store(float4* e, u32 code, const Box& b) {          // two 16-byte write-through stores (drained before the epoch moves)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f q0 = { __uint_as_float(code), b.lx, b.ly, b.lz }, q1 = { b.hx, b.hy, b.hz, 0.0f };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1" :: "v"(e), "v"(q0), "v"(q1) : "memory");
+}
+__device__ __forceinline__ void xchg_load(const float4* e, u32& code, Box& b) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f q0, q1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(e) : "memory");
+    code = __float_as_uint(q0.x); b = { q0.y, q0.z, q0.w, q1.x, q1.y, q1.z };
+}
+
+__global__ __launch_bounds__(PLOC_CHUNK, 1) void k_ploc_resident(PlocXchg* xchg, u32 epoch_base, float4* __restrict__ list_out, bvh2_node* __restrict__ nodes,
+                                                                u32* counts, u32* iters_done, u32* resident_iters, u32 n, u32 max_iters,
+                                                                const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
+    __shared__ PlocLds s;
+    __shared__ u32 s_red[8];               // [0] merges before this part, [1] all merges, [2] kept before, [3] smallest part, [4] merges of the left neighbour
+    const int tid = threadIdx.x;
+    const u32 w = blockIdx.x, G = gridDim.x, ni = n - 1u;
+    u32 C = n;
+    u32 m = n - w * (u32)PLOC_CHUNK < (u32)PLOC_CHUNK ? n - w * (u32)PLOC_CHUNK : (u32)PLOC_CHUNK;       // this part: span entries [HALO, HALO + m)
+    // the first list is the sorted leaves themselves (SetupClusters :39-55 fused): part + halos straight from the boxes
+    for (int k = tid; k < PL_SPAN; k += PLOC_CHUNK) {
+        const long long g = (long long)w * PLOC_CHUNK - PL_HALO + k;
+        if (g >= 0 && g < (long long)n && k < PL_HALO + (int)m + PL_HALO) {
+            const u32 prim = svals[g];
+            const Box b = box_gather(boxes + prim);
+            if (k >= PL_HALO && k < PL_HALO + (int)m) {
+                float* f = reinterpret_cast<float*>(leaves + g);
+                reinterpret_cast<u32*>(f)[0] = prim;
+                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
+            }
+            lds_set(s, k, (u32)g + ni, b);
+        } else s.id[k] = INV;
+        s.nn[k] = ~0ull;
+    }
+    __syncthreads();
+    u32 it = 0;
+    while (true) {
+        const int lo = w > 0u ? 0 : PL_HALO;
+        const int hi = PL_HALO + (int)m + (w + 1u < G ? PL_HALO : 0);
+        nn_pairs_fn<PLOC_CHUNK>(s, tid, lo, hi);
+        __syncthreads();
+        // merge decisions of this part's clusters (:274-320), one per thread
+        const int k = PL_HALO + tid;
+        bool mrg = false, keep = false; u32 cid = INV, pid = INV; Box cb = box_empty();
+        if (tid < (int)m) {
+            const u32 nb = (u32)s.nn[k];
+            const bool mutual = (u32)s.nn[nb] == (u32)k;
+            mrg = mutual && (u32)k < nb; keep = !mutual || mrg;
+            cid = s.id[k]; cb = lds_box(s, k);
+            if (mrg) { pid = s.id[nb]; cb = box_union(cb, lds_box(s, (int)nb)); }
+        }
+        u32 tot; const u32 ex = block_scan<PLOC_CHUNK>(s, ((u32)mrg << 16) + (u32)keep, &tot);
+        const u32 my_merges = tot >> 16, my_kept = tot & 0xFFFFu;
+        // ---- publish: the halos of the NEW list part, then {epoch, merges, kept}
+        PlocXchg* const X = xchg + (size_t)(it & 1u) * PLOC_RESIDENT_MAX_WG;
+        if (keep) {
+            const u32 p = ex & 0xFFFFu;
+            const u32 code = mrg ? (0x80000000u | (ex >> 16)) : cid;
+            if (p < (u32)PL_HALO) xchg_store(&X[w].first[p][0], code, cb);
+            if (p + (u32)PL_HALO >= my_kept) xchg_store(&X[w].last[p + (u32)PL_HALO - my_kept][0], code, cb);
+        }
+        if (tid == 0) { s_red[0] = 0u; s_red[1] = 0u; s_red[2] = 0u; s_red[3] = 0xFFFFFFFFu; s_red[4] = 0u; }
+        drain_stores();
+        __syncthreads();                                       // every thread's entry stores are in memory
+        const u32 target = epoch_base + it + 1u;
+        if (tid == 0) st_agent(&X[w].word, ((u64)target << 32) | ((u64)my_merges << 16) | (u64)my_kept);
+        // ---- everybody's word: prefix of the merges / kept before this part, the new count, the smallest part
+        if ((u32)tid < G) {
+            u64 v;
+            while (true) { v = ld_agent(&X[tid].word); if ((u32)(v >> 32) == target) break; __builtin_amdgcn_s_sleep(1); }
+            const u32 mg = (u32)(v >> 16) & 0xFFFFu, kp = (u32)v & 0xFFFFu;
+            if ((u32)tid < w) { atomicAdd(&s_red[0], mg); atomicAdd(&s_red[2], kp); }
+            if ((u32)tid + 1u == w) s_red[4] = mg;
+            atomicAdd(&s_red[1], mg); atomicMin(&s_red[3], kp);
+        }
+        __syncthreads();
+        const u32 m_ex = s_red[0], all_merges = s_red[1], k_ex = s_red[2], min_kept = s_red[3], left_merges = s_red[4];
+        u32 id = cid;
+        if (keep && mrg) { id = C - 2u - (m_ex + (ex >> 16)); node_store_plain(nodes + id, cid, pid, cb); }      // :311
+        const u32 Cn = C - all_merges;
+        ++it;
+        if (min_kept < (u32)PL_HALO || Cn < 2u * (u32)PLOC_CHUNK || it >= max_iters) {
+            // ---- hand the list to the per-iteration launches: in order, as iteration `1` of the bookkeeping expects it
+            if (keep) entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb);
+            if (w == 0u && tid == 0) { counts[1] = Cn; atomicAdd(iters_done, it); *resident_iters = it; }
+            return;
+        }
+        // ---- the new part in LDS (every read of the old one is done: block_scan's barriers and the one above), its halos from the neighbours' publication
+        if (keep) lds_set(s, PL_HALO + (int)(ex & 0xFFFFu), id, cb);
+        m = my_kept;
+        __syncthreads();
+        if (tid < 2 * PL_HALO) {
+            const bool left = tid < PL_HALO;
+            const int e = left ? tid : tid - PL_HALO;
+            const int at = left ? e : PL_HALO + (int)m + e;
+            if (left ? w > 0u : w + 1u < G) {
+                u32 code; Box b;
+                xchg_load(left ? &X[w - 1u].last[e][0] : &X[w + 1u].first[e][0], code, b);
+                if (code & 0x80000000u) code = C - 2u - ((left ? m_ex - left_merges : m_ex + my_merges) + (code & 0x7FFFFFFFu));      // a cluster the neighbour merged in this iteration
+                lds_set(s, at, code, b);
+            } else s.id[at] = INV;
+        }
+        for (int q = tid; q < PL_SPAN; q += PLOC_CHUNK) s.nn[q] = ~0ull;
+        C = Cn;
+        __syncthreads();
+    }
+}
+
+// true: the resident launch was enqueued (it leaves the list in sc.list1 and the count in counts[1], like iteration 0 of the per-iteration path)
+bool ploc_resident(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals, uint32_t epoch_base) {
+    const u32 chunks = ploc_chunks(n);
+    const u32 last = n - (chunks - 1u) * (u32)PLOC_CHUNK;
+    if (chunks < 4u || chunks > (u32)PLOC_RESIDENT_MAX_WG || last < (u32)PL_HALO || !sc.xchg) return false;
+    PlocXchg* xchg = (PlocXchg*)sc.xchg; float4* list_out = (float4*)sc.list1; bvh2_node* nodes = (bvh2_node*)d_nodes;
+    u32* counts = sc.state; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1; u32* res = sc.state + 2 * PLOC_MAX_ITERS + 2;
+    u32 nn = n, max_iters = (u32)PLOC_MAX_ITERS - 8u, eb = epoch_base;
+    const bvh_aabb* boxes = (const bvh_aabb*)d_boxes; const u32* svals = d_svals; bvh_primref* leaves = (bvh_primref*)d_leaves;
+    void* args[] = { &xchg, &eb, &list_out, &nodes, &counts, &done, &res, &nn, &max_iters, &boxes, &svals, &leaves };
+    KernelScope ks(s, "k_ploc_resident");
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_ploc_resident), dim3(chunks), dim3(PLOC_CHUNK), args, 0, s);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
 // one launch clears the per-iteration bookkeeping (two memsets + a one-thread kernel before: three launch boundaries of ~2 us in front of every build)
 __global__ __launch_bounds__(256) void k_ploc_init(u32* __restrict__ state, u32 count, uint4* __restrict__ status, u32 status_vecs, u64* __restrict__ status_tail, u32 tail_words) {
     const u32 t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
@@ -411,13 +561,13 @@ void ploc_begin_prep(const PlocScratch& sc, uint32_t n, PrepArgs& prep) {
 // is correct because chunks are taken from a ticket counter, a good guess is merely faster.
 // fresh: iteration `first` is the build's very first one (reads svals / boxes, writes the leaves: fused SetupClusters)
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals,
-                  int first, int count, int parity, bool fresh) {
+                  int first, int count, int parity, bool fresh, int skipped) {
     const u32 chunks = ploc_chunks(n);
     u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
     KernelScope ks(s, "k_ploc_iter");                   // the batch of launches is timed as one group
     for (int k = first; k < first + count; ++k) {
         const bool even = ((k + parity) & 1) == 0;
-        double guess = (double)chunks; for (int j = 0; j < k; ++j) guess *= 0.83;      // chunks expected at iteration k, generously
+        double guess = (double)chunks; for (int j = 0; j < k + skipped; ++j) guess *= 0.83;      // chunks expected at iteration k, generously (skipped: iterations a resident launch ran as "iteration 0")
         const bool wide = guess <= 1024.0;                                              // a few workgroups per CU at most: latency matters
         u32 grid = (u32)(2.0 * guess) + 8u; if (grid > (wide ? 512u : 1024u)) grid = wide ? 512u : 1024u; if (grid > chunks) grid = chunks;
         const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);

@@ -152,3 +152,44 @@ def test_batch_keeps_every_mesh_and_pipelines_a_device(pkg, orc, ctx):
             assert r2["meshes"][m]["root"] == o_root and nodes.tobytes() == o_nodes.tobytes()
     finally:
         b2.close()
+
+
+@pytest.mark.parametrize("name,n", [("uniform", 4096), ("uniform", 5000), ("uniform", 33_333), ("uniform", 100_000), ("bunny", 150_000), ("sponza", 262_144), ("uniform", 262_144),
+                                    ("uniform", 261_130), ("uniform", 4096 + 7), ("dups", 40_000), ("flat", 20_000), ("line", 6000), ("identical", 5000)])
+def test_ploc_resident_launch_is_bit_exact(pkg, orc, ctx, name, n):
+    """Round 4: lists of 4..256 chunks run their first iterations in ONE cooperative launch with the list resident in LDS (csrc/ploc.hip k_ploc_resident).
+    Node array, leaves and iteration count must equal the pinned oracle's byte for byte (test_ploc_bit_exact's bar) and the per-iteration path's; sizes whose last chunk is
+    shorter than the halo (4096 + 7, 261 130 = 255 x 1024 + 10) must fall back by themselves; degenerate scenes (duplicates, flat, collinear, identical) run the launch to its limits."""
+    mg = pkg.meshgen
+    if name == "uniform":
+        tris = mg.uniform(n, 31)
+    elif name == "bunny":
+        tris = mg.bunny_like(n, 2)
+    elif name == "sponza":
+        tris = mg.sponza_like(n, 3)
+    elif name == "dups":
+        tris = mg.uniform(n, 9); tris[::3] = tris[1]
+    elif name == "flat":
+        tris = mg.uniform(n, 8); tris["v1"][:, 2] = 0.25; tris["v2"][:, 2] = 0.25; tris["v3"][:, 2] = 0.25
+    elif name == "line":
+        tris = mg.uniform(n, 5)
+        for f in ("v1", "v2", "v3"):
+            tris[f][:, 1] = 0.0; tris[f][:, 2] = 0.0
+    else:
+        tris = np.repeat(mg.uniform(1, 3), n)
+    ref = orc.build_tree(pkg.ALGO_PLOCPP, tris)
+    outs = {}
+    for mode in ("iter", "resident"):
+        with ctx.options(ploc=mode):
+            ctx.set_profiling(2)
+            b = pkg.PLOCNew().build(ctx, tris)
+            kt = ctx.kernel_times(); ctx.set_profiling(0)
+            got = b.download()
+            outs[mode] = (got, b.timings.ploc_iterations, "k_ploc_resident" in kt)
+            assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["leaves"].tobytes() == ref["leaves"].tobytes(), (mode, name, n)
+            assert b.timings.ploc_iterations == ref["stats"]["iterations"], (mode, b.timings.ploc_iterations, ref["stats"]["iterations"])     # (also across restarts of the bookkeeping: flat / collinear scenes need thousands)
+            b2 = pkg.PLOCNew().build(ctx, tris)                       # a second build of the same size: the launch batch is sized from the first
+            assert b2.checksum() == b.checksum()
+    chunks = -(-len(tris) // 1024); last = len(tris) - (chunks - 1) * 1024
+    assert not outs["iter"][2]
+    assert outs["resident"][2] == (4 <= chunks <= 256 and last >= 16), "the resident launch runs exactly where it applies"
