@@ -577,7 +577,11 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
     // M: CalculateMortonCodes (token CalculateMortonCodesTime); values are implicit (value i = i), produced by sort pass 0
     if (key_bits == 64) launch_morton64(s, c->boxes, n, scene, reinterpret_cast<u64*>(c->keys), 60, c->sort.hist, passes, scene_next);
+#ifdef MORTON_P0_ROWS   // (cost probe: the rows land in pass 0's status rows as flag-less counts, which the owners overwrite)
+    else launch_morton(s, c->boxes, n, scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes, scene_next, n >= SORT_WIDE_MIN_N ? c->sort.status : nullptr);
+#else
     else launch_morton(s, c->boxes, n, scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes, scene_next);
+#endif
     if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
     // S: radix sort (token SortingTime)
     if (key_bits == 64) sort_pairs64(s, c->sort, reinterpret_cast<const u64*>(c->keys), nullptr, n, reinterpret_cast<u64*>(c->skeys), c->svals, 0, end_bit, true);

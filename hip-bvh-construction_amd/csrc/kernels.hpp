@@ -37,7 +37,8 @@ void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes
 void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
 void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
 void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint32_t* d_keys, uint32_t* d_vals,
-                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes, float* d_reset_next = nullptr /* Aabb::reset of another extent (the next build's) */);
+                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes, float* d_reset_next = nullptr /* Aabb::reset of another extent (the next build's) */,
+                   uint32_t* d_p0_rows = nullptr /* cost probe of -DMORTON_P0_ROWS builds only (stage_em.hip) */);
 // extended Morton code with a 60-bit budget in u64 keys (total_bits = 30 reproduces launch_morton's codes: the parity pin)
 void launch_morton64(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint64_t* d_keys, int total_bits,
                      uint32_t* d_hist /*may be null*/, int passes, float* d_reset_next = nullptr);

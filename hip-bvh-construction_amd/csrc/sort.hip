@@ -325,6 +325,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #endif
             st_agent(&status[(size_t)tile * SORT_RADIX + tid], ST_INCL | (excl + total));
         }
+#ifdef BVH_ABLATION
+        if (dig && tile > 0 && (dbg & 1)) excl = tile * total;     // timing only: the tile pretends its predecessors held what it holds, so that the scatter keeps a realistic address pattern
+#endif
         if (dig) s_gbase[tid] = gexcl + excl - s_binoff[tid];
     }
     SORT_STAMP();                                    // 4: own look-back done
@@ -346,7 +349,12 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         const u32 p = (u32)(k * NT + tid);
         if (p < valid) {
             const K kk = s_keys[p];
-            const u32 dst = (dbg & 2) ? base + p : s_gbase[(u32)(kk >> shift) & digit_mask] + p;
+#ifdef BVH_ABLATION
+            u32 dst = (dbg & 2) ? base + p : s_gbase[(u32)(kk >> shift) & digit_mask] + p;
+            if ((dbg & 1) && dst >= n) dst = n - 1u;                // (the pretended offsets can run a little past the end)
+#else
+            const u32 dst = s_gbase[(u32)(kk >> shift) & digit_mask] + p;
+#endif
             if (OUT_AOS) SORT_ST(reinterpret_cast<typename Rec::type*>(keys_out) + dst, Rec::pack(kk, s_vals[p]));
             else { SORT_ST(keys_out + dst, kk); SORT_ST(vals_out + dst, s_vals[p]); }
         }
@@ -425,7 +433,7 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
     }
 #ifdef BVH_ABLATION
     static const int env_dbg = getenv("BVH_SORT_DEBUG") ? atoi(getenv("BVH_SORT_DEBUG")) : 0;   // ablation build, measurements only: results are wrong when bits 1 / 2 are set
-    const int dbg = env_dbg | (sc.test_knobs & (8 | 32));
+    const int dbg = env_dbg | (sc.test_knobs & (8 | 32));          // (bit 128: the LAST pass runs without its look-back — in-bounds garbage nobody consumes; what a pass without look-back would save)
 #else
     const int dbg = sc.test_knobs & (8 | 32);              // BVH_OPT_SORT_TEST_KNOBS: test knobs of the helping path (results stay right)
 #endif
@@ -443,8 +451,9 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         u32* tc = sc.counters + p;
         KernelScope ks(s, "k_onesweep");
         const dim3 g(tiles), bn(SORT_NARROW_NT), bw(SortWide<K>::NT);
-#define SWEEP_B(IOTA, INA, OUTA, BB) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT, BB>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); \
-                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT, BB>), g, bn, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, dbg); } while (0)
+        const int pdbg = dbg | (((dbg & 128) && last) ? 1 : 0);
+#define SWEEP_B(IOTA, INA, OUTA, BB) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT, BB>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, pdbg); \
+                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT, BB>), g, bn, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, pdbg); } while (0)
 #define SWEEP(IOTA, INA, OUTA) SWEEP_B(IOTA, INA, OUTA, SORT_BITS)
         if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }

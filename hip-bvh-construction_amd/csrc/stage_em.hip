@@ -317,10 +317,17 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
 template <int HIST_BITS>
 __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
                                                      u32* __restrict__ keys, u32* __restrict__ vals, u32 n,
-                                                     u32* __restrict__ hist, int passes, float* reset_next) {
+                                                     u32* __restrict__ hist, int passes, float* reset_next, u32* p0_rows = nullptr) {
     if (reset_next && blockIdx.x == 0 && threadIdx.x < 6) reset_next[threadIdx.x] = threadIdx.x < 3 ? FMAX : -FMAX;     // Aabb::reset of the NEXT build's extent
     __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
     constexpr int RADIX = HIST_BITS > 0 ? (1 << HIST_BITS) : 1;
+#ifdef MORTON_P0_ROWS
+    // Cost probe (second half): what would it cost this kernel to ALSO leave the first sort pass's per-tile digit counts (one 256-word row per
+    // 6656-key sort tile, so that pass 0 needs no look-back)?  Every workgroup takes a contiguous run of 256-key tiles instead of a grid-strided one, counts digit 0
+    // per sort tile in LDS and flushes a row with one atomic per non-empty bin whenever its run crosses a sort-tile boundary.  Timing only: nothing consumes the rows.
+    __shared__ u32 s_row[256];
+    if (p0_rows) s_row[threadIdx.x] = 0;
+#endif
     __shared__ u32 s_hist[HIST_BITS > 0 ? 4 * RADIX : 1];
     if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext);
     if (HIST_BITS > 0) for (int i = threadIdx.x; i < passes * RADIX; i += EM_BLOCK) s_hist[i] = 0;
@@ -329,7 +336,26 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
     const float lo[3] = { s_lo[0], s_lo[1], s_lo[2] }, ext[3] = { s_ext[0], s_ext[1], s_ext[2] };
     // tiles in descending order: stage E wrote the boxes in ascending order just before, so the last ones are the ones still in the caches
     const u32 ntile = (n + EM_BLOCK - 1) / EM_BLOCK;
+#ifdef MORTON_P0_ROWS
+    const u32 per = (ntile + gridDim.x - 1) / gridDim.x;
+    const u32 t_begin = p0_rows ? blockIdx.x * per : blockIdx.x, t_end = p0_rows ? min(ntile, t_begin + per) : ntile, t_step = p0_rows ? 1u : gridDim.x;
+    u32 cur_row = 0xFFFFFFFFu;
+    for (u32 tile = t_begin; tile < t_end; tile += t_step) {
+        if (p0_rows) {
+            const u32 row = (ntile - 1u - tile) / ((512 * 13) / EM_BLOCK);      // (the wide sort tile: 512 threads x 13 keys)
+            if (row != cur_row) {                              // (uniform)
+                if (cur_row != 0xFFFFFFFFu) {
+                    __syncthreads();
+                    const u32 c = s_row[threadIdx.x]; if (c) atomicAdd(&p0_rows[(size_t)cur_row * 256 + threadIdx.x], c);
+                    s_row[threadIdx.x] = 0;
+                    __syncthreads();
+                }
+                cur_row = row;
+            }
+        }
+#else
     for (u32 tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+#endif
 #if MORTON_REVERSE
         const u32 i = (ntile - 1u - tile) * EM_BLOCK + threadIdx.x;
 #else
@@ -344,8 +370,17 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
         if (vals) vals[i] = i;                                   // :384
         if (HIST_BITS > 0) {
             for (int ps = 0; ps < passes; ++ps) atomicAdd(&s_hist[ps * RADIX + ((code >> (ps * HIST_BITS)) & (RADIX - 1))], 1u);
+#ifdef MORTON_P0_ROWS
+            if (p0_rows) atomicAdd(&s_row[code & 255u], 1u);
+#endif
         }
     }
+#ifdef MORTON_P0_ROWS
+    if (p0_rows && cur_row != 0xFFFFFFFFu) {
+        __syncthreads();
+        const u32 c = s_row[threadIdx.x]; if (c) atomicAdd(&p0_rows[(size_t)cur_row * 256 + threadIdx.x], c);
+    }
+#endif
     if (HIST_BITS > 0) {
         __syncthreads();
         u32* copy = hist + (blockIdx.x % SORT_HIST_COPIES) * SORT_HIST_STRIDE;      // (kernels.hpp: why there are several copies)
@@ -408,11 +443,11 @@ void launch_morton_plan(hipStream_t s, const void* d_scene, int* d_out, int tota
 }
 
 void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
-                   u32* d_hist, int hist_bits, int passes, float* d_reset_next) {
+                   u32* d_hist, int hist_bits, int passes, float* d_reset_next, u32* d_p0_rows) {
     const dim3 g(em_grid(n)), b(EM_BLOCK);
     KernelScope ks(s, "k_morton");
-    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes, d_reset_next);
-    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0, d_reset_next);
+    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes, d_reset_next, d_p0_rows);
+    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0, d_reset_next, (u32*)nullptr);
 }
 
 void launch_morton64(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, uint64_t* d_keys, int total_bits, u32* d_hist, int passes, float* d_reset_next) {
