@@ -193,3 +193,53 @@ def test_ploc_resident_launch_is_bit_exact(pkg, orc, ctx, name, n):
     chunks = -(-len(tris) // 1024); last = len(tris) - (chunks - 1) * 1024
     assert not outs["iter"][2]
     assert outs["resident"][2] == (4 <= chunks <= 256 and last >= 16), "the resident launch runs exactly where it applies"
+
+
+class _RawDevice:
+    """a device address as a torch tensor (no copy)"""
+    def __init__(self, ptr, n, typestr): self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def test_seventy_million_triangles_cross_the_4_gib_offset(pkg, orc):
+    """Maximum sizes (the boundary accepts n < 2^30; tools/large_n.py ran 50 M .. 400 M): 70 M triangles = 4.2 GiB of 64-byte records, so every byte offset into the
+    input that was computed in 32 bits would wrap.  The mesh is generated on the device; both schedulers of HPLOC and of the single-pass LBVH must agree (bvh_checksum),
+    the sorted keys are checked on the device, the values are a permutation (sum), and the LBVH tree is downloaded and run through the oracle's validator."""
+    import torch
+    n = 70_000_000
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    d = torch.zeros((n, 16), device="cuda", dtype=torch.float32)
+    for lo in range(0, n, 10_000_000):
+        hi = min(n, lo + 10_000_000)
+        c = torch.rand((hi - lo, 3), device="cuda", generator=g)
+        for v in range(3):
+            d[lo:hi, 3 * v:3 * v + 3] = c + 0.001 * (torch.rand((hi - lo, 3), device="cuda", generator=g) - 0.5)
+    torch.cuda.synchronize()
+    big = pkg.Context(0)
+    try:
+        for algo, opt, modes in ((pkg.ALGO_HPLOC, "hploc", ("block", "async")), (pkg.ALGO_SINGLEPASS, "lbvh", ("block", "single"))):
+            sums = []
+            for mode in modes:
+                big.set_option(opt, mode)
+                b = pkg.BUILDERS[algo]().build(big, d, on_device=True, n=n)
+                r = b.result
+                assert r.n_leaves == n
+                keys = torch.as_tensor(_RawDevice(r.d_sorted_keys, n, "<u4"), device="cuda").to(torch.int64)
+                assert bool((keys[1:] >= keys[:-1]).all()), "sorted keys"
+                del keys
+                vals = torch.as_tensor(_RawDevice(r.d_sorted_vals, n, "<u4"), device="cuda").to(torch.int64)
+                assert int(vals.sum()) == n * (n - 1) // 2 and int(vals.max()) == n - 1, "values are a permutation of 0..n-1"
+                del vals
+                sums.append(b.checksum())
+                if algo == pkg.ALGO_SINGLEPASS and mode == "block":
+                    got = b.download()
+                    assert orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
+                    root = got["nodes"][got["root"]]; sc = got["scene"][0]
+                    assert np.array_equal(root["min"], sc["min"]) and np.array_equal(root["max"], sc["max"])
+                    # the last triangle's box (byte offset 4 479 999 936 in the input) is the leaf that carries primitive n - 1
+                    last = d[n - 1, :9].cpu().numpy().reshape(3, 3)
+                    leaf = got["nodes"][n - 1 + int(np.nonzero(got["sorted_vals"] == n - 1)[0][0])]
+                    assert np.array_equal(leaf["min"], last.min(axis=0)) and np.array_equal(leaf["max"], last.max(axis=0))
+                    del got
+            assert sums[0] == sums[1], f"{opt}: the two schedulers built different trees"
+    finally:
+        big.close()
