@@ -172,6 +172,56 @@ __device__ __forceinline__ v2f_t area_pair(v2f_t lx, v2f_t ly, v2f_t lz, v2f_t h
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// The per-pass digit histograms of one key (k_morton / k_morton64 / k_hist): `passes` LDS atomics per lane.  A spatially coherent input (a real mesh's usual state; the
+// benchmark's uniform mesh is the opposite) hands a wave 64 keys that share their high digits, and 64 LDS atomics on one address serialise: k_morton on the Morton-ordered
+// 10 M mesh took 0.0912 ms against 0.0618 in random order, k_morton64 0.1205 against 0.0796, the stand-alone sort of sorted keys 0.286 against 0.241 (tools/ab_morton_order.py).
+// Grouped counting: the lanes that hold the digit of the wave's first active lane are counted by ONE atomic of their lowest lane, the others add for themselves.  Measured
+// forms (round 4, same tool; random / Morton order): behind divergent branches (mode 2) k_morton 0.0648 / 0.0640; branch-free (mode 3: every lane issues one ds_add, the
+// group's other lanes add 0 to a word of their own) 0.0635 / 0.0630 — the default for the four digits of k_morton: +1.7 us on the benchmark's random order, -28 us on a
+// coherent one; only when the wave's keys share their TOP digit (modes 1 / 4: one comparison, wave-uniform branch) 0.072 / 0.076 for k_morton (two code paths cost it more
+// than they save) but right for the eight digits of k_morton64 (0.0806 / 0.098; always grouped: 0.094 / 0.094) and for k_hist (0.245 / 0.250).
+#ifndef MORTON_GROUP
+#define MORTON_GROUP 3       // k_morton (4 digits)
+#endif
+#ifndef MORTON64_GROUP
+#define MORTON64_GROUP 4     // k_morton64 (8 digits)
+#endif
+#ifndef SORT_HIST_GROUP
+#define SORT_HIST_GROUP 4    // k_hist (stand-alone sort)
+#endif
+// MODE: 0 = plain atomics, 1 = grouped when the top digit is shared, 2 = always grouped, 3 = always grouped and branch-free (every lane issues one ds_add: the group's other
+// lanes add 0 to a word of their own in `pad`, 64 words), 4 = the branch-free form when the top digit is shared, plain atomics otherwise.
+template <int MODE, typename DigitOf>
+__device__ __forceinline__ void hist_add_passes(u32* hist, int passes, int stride, DigitOf digit_of, u32* pad = nullptr) {
+    bool grouped = MODE == 2 || MODE == 3;
+    if (MODE == 1 || MODE == 4) {
+        const u32 top = digit_of(passes - 1);
+        grouped = __ballot(top == (u32)__builtin_amdgcn_readfirstlane((int)top)) == __ballot(true);     // (uniform over the active lanes)
+    }
+    if (MODE == 3 || (MODE == 4 && grouped)) {
+        const u32 lane = lane_id();
+        for (int ps = 0; ps < passes; ++ps) {
+            const u32 d = digit_of(ps);
+            const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+            const u64 same = __ballot(d == d0);
+            const bool mine = d == d0, lead = lane == (u32)__builtin_ctzll(same);
+            u32* at = (mine && !lead) ? pad + lane : hist + ps * stride + d;
+            atomicAdd(at, lead ? (u32)__popcll(same) : (mine ? 0u : 1u));
+        }
+    } else if (grouped) {
+        const u64 lt = lanemask_lt();
+        for (int ps = 0; ps < passes; ++ps) {
+            const u32 d = digit_of(ps);
+            const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+            const u64 same = __ballot(d == d0);
+            if (d != d0) atomicAdd(&hist[ps * stride + d], 1u);
+            else if ((same & lt) == 0ull) atomicAdd(&hist[ps * stride + d0], (u32)__popcll(same));
+        }
+    } else {
+        for (int ps = 0; ps < passes; ++ps) atomicAdd(&hist[ps * stride + digit_of(ps)], 1u);
+    }
+}
+
 // 64-bit augmented key of sorted position i (Morton key in the high word, position in the low word)
 __device__ __forceinline__ u64 aug_key(const u32* __restrict__ keys, u32 i) { return ((u64)keys[i] << 32) | i; }
 

@@ -63,16 +63,17 @@ template <typename K>
 __global__ __launch_bounds__(SORT_BLOCK) void k_hist(const K* __restrict__ keys, u32 n, int start_bit, int end_bit, int passes,
                                                      u32* __restrict__ hist) {
     __shared__ u32 s_hist[SORT_MAX_PASSES * SORT_RADIX];
+    __shared__ u32 s_pad[SORT_HIST_GROUP >= 3 ? 64 : 1];
     for (int i = threadIdx.x; i < passes * SORT_RADIX; i += SORT_BLOCK) s_hist[i] = 0;
     __syncthreads();
     const u32 stride = gridDim.x * SORT_BLOCK;
     for (u32 i = blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += stride) {
         const K k = keys[i];
-        for (int p = 0; p < passes; ++p) {
+        hist_add_passes<SORT_HIST_GROUP>(s_hist, passes, SORT_RADIX, [&](int p) {
             const int sh = start_bit + p * SORT_BITS;
             const int w = min(SORT_BITS, end_bit - sh);
-            atomicAdd(&s_hist[p * SORT_RADIX + ((u32)(k >> sh) & ((1u << w) - 1u))], 1u);
-        }
+            return (u32)(k >> sh) & ((1u << w) - 1u);
+        }, s_pad);
     }
     __syncthreads();
     u32* copy = hist + (blockIdx.x % SORT_HIST_COPIES) * SORT_HIST_STRIDE;

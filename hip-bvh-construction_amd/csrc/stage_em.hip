@@ -289,6 +289,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
     if (reset_next && blockIdx.x == 0 && threadIdx.x < 6) reset_next[threadIdx.x] = threadIdx.x < 3 ? FMAX : -FMAX;     // Aabb::reset of the NEXT build's extent
     __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
     __shared__ u32 s_hist[8 * 256];
+    __shared__ u32 s_pad[MORTON64_GROUP >= 3 ? 64 : 1];
     if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext, total_bits);
     for (int i = threadIdx.x; i < passes * 256; i += EM_BLOCK) s_hist[i] = 0;
     __syncthreads();
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
         const float p[3] = { ((b.hx + b.lx) * 0.5f - lo[0]) / ext[0], ((b.hy + b.ly) * 0.5f - lo[1]) / ext[1], ((b.hz + b.lz) * 0.5f - lo[2]) / ext[2] };
         const u64 code = encode64(m, p[m.axis[0]], p[m.axis[1]], p[m.axis[2]]);
         keys[i] = code;
-        for (int ps = 0; ps < passes; ++ps) atomicAdd(&s_hist[ps * 256 + ((u32)(code >> (ps * 8)) & 255u)], 1u);
+        hist_add_passes<MORTON64_GROUP>(s_hist, passes, 256, [&](int ps) { return (u32)(code >> (ps * 8)) & 255u; }, s_pad);
     }
     __syncthreads();
     u32* copy = hist + (blockIdx.x % SORT_HIST_COPIES) * SORT_HIST_STRIDE;
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
     if (p0_rows) s_row[threadIdx.x] = 0;
 #endif
     __shared__ u32 s_hist[HIST_BITS > 0 ? 4 * RADIX : 1];
+    __shared__ u32 s_pad[MORTON_GROUP >= 3 ? 64 : 1];
     if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext);
     if (HIST_BITS > 0) for (int i = threadIdx.x; i < passes * RADIX; i += EM_BLOCK) s_hist[i] = 0;
     __syncthreads();
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
         keys[i] = code;
         if (vals) vals[i] = i;                                   // :384
         if (HIST_BITS > 0) {
-            for (int ps = 0; ps < passes; ++ps) atomicAdd(&s_hist[ps * RADIX + ((code >> (ps * HIST_BITS)) & (RADIX - 1))], 1u);
+            hist_add_passes<MORTON_GROUP>(s_hist, passes, RADIX, [&](int ps) { return (code >> (ps * HIST_BITS)) & (u32)(RADIX - 1); }, s_pad);
 #ifdef MORTON_P0_ROWS
             if (p0_rows) atomicAdd(&s_row[code & 255u], 1u);
 #endif

@@ -243,3 +243,47 @@ def test_seventy_million_triangles_cross_the_4_gib_offset(pkg, orc):
             assert sums[0] == sums[1], f"{opt}: the two schedulers built different trees"
     finally:
         big.close()
+
+
+@pytest.mark.parametrize("pattern", ["sorted", "constant", "two_values_per_wave", "shared_top_digit", "runs_of_17"])
+@pytest.mark.parametrize("n", [1_000_003, 5_003])
+def test_sort_histograms_on_coherent_keys(pkg, ctx, pattern, n):
+    """The digit histograms count a wave's keys in groups when they share digits (csrc/common.hpp hist_add_passes: k_hist here, k_morton / k_morton64 in the builds — a
+    Morton-ordered mesh is exactly this input).  Key patterns that exercise the grouped paths — every lane in the first lane's group, two groups, a shared top digit with random
+    low digits, groups that straddle waves — with n not a multiple of 64 (partial last wave): stable-argsort parity for 30- and 32-bit sorts."""
+    rng = np.random.default_rng(len(pattern) * 7 + n)
+    if pattern == "sorted": keys = np.sort(rng.integers(0, 2**30, n, dtype=np.uint64)).astype(np.uint32)
+    elif pattern == "constant": keys = np.full(n, 0x2AAAAAAA, np.uint32)
+    elif pattern == "two_values_per_wave": keys = np.where(np.arange(n) % 3 == 0, 0x00FF00FF, 0x3F00FF00).astype(np.uint32)
+    elif pattern == "shared_top_digit": keys = (np.uint32(0x2A000000) | rng.integers(0, 2**24, n, dtype=np.uint64).astype(np.uint32))
+    else: keys = np.repeat(rng.integers(0, 2**30, n // 17 + 1, dtype=np.uint64).astype(np.uint32), 17)[:n]
+    L = pkg.lib()
+    dk, ok, ov = ctx.upload(keys), ctx.alloc(n * 4), ctx.alloc(n * 4)
+    for bits in (30, 32):
+        assert L.bvh_sort_pairs(ctx.handle, dk.ptr, None, n, ok.ptr, ov.ptr, 0, bits) == 0
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(ok.download(np.uint32, n), keys[order])
+        assert np.array_equal(ov.download(np.uint32, n), order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("bits", [30, 60])
+def test_builds_on_a_morton_ordered_mesh(pkg, orc, ctx, bits):
+    """the same grouped counting inside the builds (k_morton, k_morton64): a mesh re-ordered by its own Morton order — single-pass LBVH byte-exact against the oracle,
+    HPLOC valid with the same SAH as the oracle's, the sorted keys ascending and the values a permutation, for both key widths"""
+    tris = pkg.meshgen.uniform(300_007, 5)
+    order = pkg.BUILDERS[pkg.ALGO_SINGLEPASS]().build(ctx, tris).download()["sorted_vals"]
+    tris = np.ascontiguousarray(tris[order]); n = len(tris)
+    d = ctx.upload(tris)
+    got = pkg.BUILDERS[pkg.ALGO_SINGLEPASS]().build_ex(ctx, n, tris=d, morton_bits=bits).download()
+    k = got["sorted_keys"]
+    assert bool(np.all(k[1:] >= k[:-1])) and np.array_equal(np.sort(got["sorted_vals"]), np.arange(n, dtype=np.uint32))
+    assert orc.validate_bvh2(got["nodes"], None, got["root"], n, 0) == 0
+    ref = orc.build_tree(1, tris, bits)
+    assert np.array_equal(k, ref["skeys"]) and np.array_equal(got["sorted_vals"], ref["svals"])
+    assert got["nodes"].tobytes() == ref["nodes"].tobytes()
+    h = pkg.HPLOC().build_ex(ctx, n, tris=d, morton_bits=bits)
+    hg = h.download()
+    assert orc.validate_bvh2(hg["nodes"], hg["leaves"], hg["root"], n, 1) == 0
+    if True:
+        ref = orc.build_tree(3, tris, bits)
+        assert abs(h.sah_cost() - orc.sah_bvh2(ref["nodes"], ref["leaves"], ref["root"], n, 1)[0]) <= 1e-9 * max(1.0, h.m_cost)
