@@ -238,6 +238,30 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
 #endif
 }
 
+// The same search with ONE task on the whole wave (tile kernel, HPB_WIDE: the rounds in which only one half of the wave still has a task — a pass that got a single task,
+// or the longer-running task of an unequal pair: 19 of a tile's 56 wave-rounds on the 10 M uniform mesh, tools/model_hploc.py's task trees).  The task's own half evaluates the
+// pairs (slot, slot + 1..4), the other half — whose lanes hold the same 32 clusters, read from the task's LDS list — the pairs (slot, slot + 5..8): four candidates per lane
+// instead of eight, the keys meet in the task's 32 words of nn through the same LDS minima (tie rule unchanged: the key carries the other end's slot).
+// b: the cluster of this lane's slot; nb: the cluster of slot + off (off = 0 in the task's half, 4 in the helping half); ai = first word of the task's half + slot.
+__device__ __forceinline__ int nn_search_wide(const Box& b, Box nb, u32 off, u32 cnt, int ai, int slot, int lane, u64* nn) {
+    nn[lane] = ~0ull;
+    compiler_fence();
+#pragma unroll
+    for (int rr = 1; rr <= HP_RADIUS / 2; ++rr) {
+        nb = box_shl1(nb);                                                       // box of slot + off + rr (a shift across the wave's middle only feeds masked pairs)
+        const float ex = fmaxf(nb.hx, b.hx) - fminf(nb.lx, b.lx), ey = fmaxf(nb.hy, b.hy) - fminf(nb.ly, b.ly), ez = fmaxf(nb.hz, b.hz) - fminf(nb.lz, b.lz);
+        const float half_area = ex * ey + ex * ez + ey * ez;
+        const u32 ab = __float_as_uint(half_area + half_area);
+        const u32 far = (u32)slot + off + (u32)rr;
+        if (far < cnt) {
+            atomicMin(reinterpret_cast<unsigned long long*>(nn + ai + (int)off + rr), ((unsigned long long)ab << 32) | (u32)slot);
+            atomicMin(reinterpret_cast<unsigned long long*>(nn + ai), ((unsigned long long)ab << 32) | far);
+        }
+    }
+    compiler_fence();
+    return (int)(u32)nn[lane];
+}
+
 // The same search for the tile kernel's INTERLEAVED lane layout (HPB_IL): lanes 0..15 of a half hold the task's even slots, lanes 16..31 the odd ones, and
 // every lane also holds o = the box of slot + 1 (read from the LDS list together with its own record).  The box of slot + r is then a 16-lane ROW shift of
 // b (r even: by r / 2) or of o (r odd: by (r - 1) / 2; r = 1: o itself) — a DPP operand of the union's v_min / v_max, no data movement: the 48 v_mov_b32_dpp of
@@ -411,7 +435,7 @@ struct WaveList {            // k_hploc_ext: a wave's two 32-slot work lists wit
 // One task per 32-lane half.  In: have / final_ (uniform per half), cnt, and the lane's cluster (tag, b; invalid beyond cnt) as loaded from the list.
 // Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
 // IL: interleaved lane layout (nn_search_il): slot is NOT lane & 31; below = the half's lanes that hold lower slots; o_in = box of slot + 1.
-template <bool AGENT, bool IL, typename List>
+template <bool AGENT, bool IL, typename List, bool WIDE = false>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
                                                 const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
                                                 u32 below = 0u) {
@@ -420,10 +444,27 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
     Box b = b_io;
     if (!IL) below = (1u << slot) - 1u;
     const u32 threshold = final_ ? 1u : HP_HALF;
-    bool moved = nl >= cnt;                           // every slot already sits at base + slot
+    // a task that needs no round only left-packs its right child's clusters (done up front: a helping half's b does not survive the loop, HPB_WIDE)
+    if (have && cnt <= threshold && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);
     while (__ballot(have && cnt > threshold)) {
         const bool act = have && cnt > threshold;
         u32 nbr;
+        bool wide = false;
+        u64 am = 0ull;
+        if (WIDE) { am = __ballot(act); wide = ((u32)am == 0u) != ((u32)(am >> 32) == 0u); }     // exactly one half of the wave runs a task (wave-uniform)
+        if (WIDE && wide) {
+            // nn_search_wide: the other half helps.  The task's parameters come from its half's first lane; every lane (re)reads the cluster of its slot from the task's
+            // list (the task's own lanes hold exactly that already) and the one its chain starts from.  b_io of a helping half is clobbered: the tile kernel does not use it.
+            const int ah = (u32)am == 0u ? 32 : 0;
+            const u32 a_cnt = (u32)__builtin_amdgcn_readlane((int)cnt, ah), a_base = (u32)__builtin_amdgcn_readlane((int)base, ah);
+            const u32 a_nl = (u32)__builtin_amdgcn_readlane((int)nl, ah), a_rbase = (u32)__builtin_amdgcn_readlane((int)rbase, ah);
+            const u32 off = hbase == ah ? 0u : (u32)(HP_RADIUS / 2);
+            const u32 t1 = (u32)slot + off;
+            const u32 p0 = (u32)slot < a_nl ? a_base + (u32)slot : a_rbase + (u32)slot, p1 = t1 < a_nl ? a_base + t1 : a_rbase + t1;
+            b = list.load_box(p0 < lim ? p0 : lim);
+            const Box st = list.load_box(p1 < lim ? p1 : lim);
+            nbr = (u32)nn_search_wide(b, st, off, a_cnt, ah + slot, slot, lane, nn) & 31u;
+        } else
         if (IL) { const u32 p1 = (u32)slot + 1u < nl ? base + (u32)slot + 1u : rbase + (u32)slot + 1u; nbr = (u32)nn_search_il(b, list, p1 < lim ? p1 : lim, act, cnt, slot, nn + hbase) & 31u; }
         else nbr = (u32)nn_search(b, act, cnt, lane, slot, nn) & 31u;
         // mergeClusters (:126-190): the neighbour's choice (low word of its key) and its record, read in one go
@@ -476,7 +517,7 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
         typename List::Tag t2; Box b2;
         list.load(base + (u32)slot < lim ? base + (u32)slot : lim, t2, b2);
         if (act) {
-            cnt = newcnt; nl = 32u; moved = true;
+            cnt = newcnt; nl = 32u;
             b = b2; tag = (u32)slot < newcnt ? t2 : List::invalid_tag();
         }
 #ifdef ABL_EXTRA_TRIP    // in-situ probe: one more DEPENDENT LDS round trip per round (a 4-byte read whose address depends on the read-back, result waited for)
@@ -485,7 +526,6 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
           if (x == 0x12345u) cnt = 0u; }
 #endif
     }
-    if (have && !moved && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);   // no round ran: left-pack the right child's clusters
     tag_io = tag; cnt_io = cnt; b_io = b;
 }
 
@@ -628,6 +668,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
                          //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
 #endif
+#ifndef HPB_WIDE
+#define HPB_WIDE 0       // A/B switch (off: measured, no gain — DESIGN.md section 9 row 64).  1: a round in which only one half of the wave still has a task runs that task on the whole wave (nn_search_wide: four candidates per lane)
+#endif
 #ifndef HPB_PREPROBE
 #define HPB_PREPROBE 1   // 1: two probes at p - 8 / p + 9 decide most gaps before the binary searches for a node's range (the searches run compacted, one gap per thread)
 #endif
@@ -638,8 +681,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #define HPB_PRIO 0       // A/B switch (off): s_setprio in the tile kernel — 1: a level's waves run at a priority that grows as the level thins out (<= 2 tasks: 3, <= 4: 2,
 #endif                   //    <= 8: 1); 2: the whole level loop above staging / ranges / hand-over; 3: staging and ranges above the level loop.  Measured: DESIGN.md section 9
 #ifndef HPB_LEAN
-#define HPB_LEAN 0       // 1: 20.3 KB of LDS instead of 22.9 (eight workgroups per CU): the key window shares its storage with the rounds' key words and is
-#endif                   //    re-read for the hand-over; level counters sized for the key type
+#define HPB_LEAN 1       // 1 (default since round 4): 20.3 KB of LDS instead of 22.9 — EIGHT workgroups per CU: the key window shares its storage with the rounds' key words and is
+#endif                   //    re-read for the hand-over; level counters sized for the key type.  Round 3 measured it slower (eight waves per SIMD allow 64 VGPRs and the kernel
+                         //    needed 70: spills in the rounds); since the rounds no longer keep a task's box and tag alive for a store behind the loop (ploc_rounds_lds: the
+                         //    left-pack of a task that needs no round runs up front; 70 -> 66 VGPRs, tile kernel 0.644 -> 0.633 ms by itself) the kernel fits 64 registers with
+                         //    two spilled: 10 M 0.6396 -> 0.6255 ms, 2 M 0.158 -> 0.1535 (production flags, three runs each; HPB_OCC = 8 goes with it)
 #if HPB_LEAN
     constexpr int NLV = NLEV;
     constexpr size_t KN_BYTES = sizeof(K) * (T + 2 * KM) > sizeof(u64) * (NT + 8) ? sizeof(K) * (T + 2 * KM) : sizeof(u64) * (NT + 8);
@@ -885,7 +931,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false, HPB_IL != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below);
+            ploc_rounds_lds<false, HPB_IL != 0, TileList, (HPB_WIDE != 0 && HPB_IL == 0)>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
 #if HPB_DEPS
             if (have && slot == 0) {                 // tell the parent, if it is a task of this tile
@@ -1253,7 +1299,10 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
 #define HPB_NT 256
 #endif
 #ifndef HPB_OCC
-#define HPB_OCC 7
+#define HPB_OCC 8        // waves per SIMD = workgroups per CU of the tile kernel (HPB_LEAN: 8 x 20.3 KB of LDS, 64 VGPRs)
+#endif
+#ifndef HPB_OCC64
+#define HPB_OCC64 7      // the u64-key instantiation keeps more registers (96-bit augmented keys, wider key window)
 #endif
 static void hpb_config(int* t, int* nt, int* occ) {
     *t = HPB_T; *nt = HPB_NT; *occ = HPB_OCC;
@@ -1278,7 +1327,7 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
 #define HPB_LAUNCH(KK, TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<KK, TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg, (const float4*)sc.leaf_tris)
     { KernelScope ks(s, "k_hploc_block");
-      if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC);
+      if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC64);
       else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, 6);
       else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC); }
 #undef HPB_LAUNCH
