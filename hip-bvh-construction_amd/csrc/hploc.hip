@@ -1301,6 +1301,9 @@ void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int k
 #ifndef HPB_OCC
 #define HPB_OCC 8        // waves per SIMD = workgroups per CU of the tile kernel (HPB_LEAN: 8 x 20.3 KB of LDS, 64 VGPRs)
 #endif
+#ifndef HPB_OCC_1024
+#define HPB_OCC_1024 6    // (the 1024-leaf / 512-thread shape of the A/B builds)
+#endif
 #ifndef HPB_OCC64
 #define HPB_OCC64 7      // the u64-key instantiation keeps more registers (96-bit augmented keys, wider key window)
 #endif
@@ -1328,7 +1331,7 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg, (const float4*)sc.leaf_tris)
     { KernelScope ks(s, "k_hploc_block");
       if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC64);
-      else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, 6);
+      else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, HPB_OCC_1024);
       else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC); }
 #undef HPB_LAUNCH
     if (dbg) return;
