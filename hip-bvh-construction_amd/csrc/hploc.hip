@@ -705,6 +705,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
     __shared__ u32 s_cnt[NLV], s_off[NLV];
+    __shared__ u64 s_lvmask[2];                      // the non-empty levels (bit lv of word lv / 64): the level loop visits only those
     __shared__ u32 s_npub, s_nready, s_qbase, s_ncand;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
 #if !HPB_LEAN
@@ -850,10 +851,16 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         s_task[s_off[my_lv[i]] + before + my_pos[i]] = (unsigned short)my_gap[i];
     }
     __syncthreads();
-    if (tid < NLV) s_cnt[tid] = lv_total(s_cnt[tid]);                                 // the level loop reads plain counts
+    if (tid < 128) {                                                                  // (waves 0 and 1; NLV <= 128)
+        const u32 tot = tid < NLV ? lv_total(s_cnt[tid]) : 0u;
+        if (tid < NLV) s_cnt[tid] = tot;                                              // the level loop reads plain counts
+        const u64 m = __ballot(tot != 0u);
+        if (lane == 0) s_lvmask[wave] = m;
+    }
     __syncthreads();
 #else
     for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)my_gap[i];
+    if (tid < 128) { const u64 m = __ballot(tid < NLV && s_cnt[tid < NLV ? tid : 0] != 0u); if (lane == 0) s_lvmask[wave] = m; }
     __syncthreads();
 #endif
 #if HPB_DEPS
@@ -889,9 +896,14 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #endif                   //    to bits 30..31 of its parent's m_range word (if the parent is a local task); a task waits (s_sleep) until its word shows as many arrivals as it
                          //    has big children.  Waves walk their static share of the level-sorted task list in order, so whatever a task waits for sits EARLIER in some
                          //    wave's sequence: no cycle.  A wave's LDS operations execute in order: the survivors a task wrote are in LDS before its arrival count is.
-    for (int lv = 0; lv < NLEV; ++lv) {
+    // (only the non-empty levels are visited — ~5 of 64: a scan over s_cnt cost a dependent LDS read per empty level)
+    u64 lvm[2];
+    for (int i = 0; i < 2; ++i) { const u64 m = s_lvmask[i]; lvm[i] = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(m >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)m); }
+    for (int lw = 0; lw < (NLEV + 63) / 64; ++lw)
+    while (lvm[lw]) {
+        const int lv = lw * 64 + (int)__builtin_ctzll(lvm[lw]);                        // block-uniform
+        lvm[lw] &= lvm[lw] - 1ull;
         const u32 c = s_cnt[lv];
-        if (!c) continue;                            // block-uniform
         const u32 base = s_off[lv];
 #if HPB_PRIO == 1
         if (c <= 2u) __builtin_amdgcn_s_setprio(3); else if (c <= 4u) __builtin_amdgcn_s_setprio(2); else if (c <= 8u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
