@@ -668,6 +668,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
                          //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
 #endif
+#ifndef HPB_STAGE_SERIAL_GATHER
+#define HPB_STAGE_SERIAL_GATHER 1   // 1: a thread's PER box gathers go out one after the other (0: together — measured slower at 10 M, see the staging)
+#endif
 #ifndef HPB_WIDE
 #define HPB_WIDE 0       // A/B switch (off: measured, no gain — DESIGN.md section 9 row 64).  1: a round in which only one half of the wave still has a task runs that task on the whole wave (nn_search_wide: four candidates per lane)
 #endif
@@ -729,12 +732,45 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __builtin_amdgcn_s_setprio(2);
 #endif
     // ---- stage the block: leaves (SetupClusters :44-47, fused), keys -------------------------------------------------
+    // Every load of a dependency level is issued before the first one is waited for: the key window and the PER primitive indices together, then the PER box gathers.
+    // (Indices are clamped, not branched around: with a branch per leaf the compiler emitted index -> wait -> box -> wait per leaf and then the key window one load
+    // at a time — seven dependent HBM round trips at the start of every tile where two suffice; round 4, found in the ISA.)
+    // The PER box gathers of a thread are the exception (HPB_STAGE_SERIAL_GATHER): both in flight at once measured SLOWER at 10 M, where the gather misses every cache
+    // (tile kernel, production flags, ms at 10 M / 2 M: before 0.6115 / 0.149; everything together 0.6235 / 0.144; gathers one after the other 0.595 / 0.143).
+    constexpr int KW = (T + 2 * KM + NT - 1) / NT;
+    K kwin[KW];
+#pragma unroll
+    for (int q = 0; q < KW; ++q) {
+        const int k = tid + q * NT;
+        const long long j = (long long)g0 - KM + k;
+        const bool in = k < T + 2 * KM && j >= 0 && j < (long long)n;
+        kwin[q] = skeys[in ? j : (long long)g0];
+        if (!in) kwin[q] = (K)0;
+    }
+    u32 prim_[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const u32 k = (u32)tid + (u32)i * NT; prim_[i] = svals[g0 + (k < nleaf ? k : nleaf - 1u)]; }
+    Box box_[PER];
+    if (tris) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) box_[i] = tri_box_gather(tris + (size_t)prim_[i] * 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            box_[i] = box_gather(boxes + prim_[i]);
+#if HPB_STAGE_SERIAL_GATHER
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(box_[i].lx), "+v"(box_[i].ly), "+v"(box_[i].lz), "+v"(box_[i].hx), "+v"(box_[i].hy), "+v"(box_[i].hz) :: "memory");
+#endif
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KW; ++q) { const int k = tid + q * NT; if (k < T + 2 * KM) s_key[k] = kwin[q]; }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const u32 k = (u32)tid + (u32)i * NT;
         if (k < nleaf) {
-            const u32 g = g0 + k, prim = svals[g];
-            const Box b = tris ? tri_box_gather(tris + (size_t)prim * 4) : box_gather(boxes + prim);
+            const u32 g = g0 + k, prim = prim_[i];
+            const Box b = box_[i];
             float* f = reinterpret_cast<float*>(leaves + g);
             reinterpret_cast<u32*>(f)[0] = prim;
             f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
@@ -751,7 +787,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         }
         if (__float_as_uint(acc) == 0x7fffabcdu) e_ir[0] = 0u; }
 #endif
-    for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
     if (tid < NLV) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; s_ncand = 0u; }
     __syncthreads();
@@ -972,7 +1007,18 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     if (dbg == 3) return;
 #if HPB_LEAN
     // the rounds' key words overwrote the key window (every thread is past the level loop's last barrier): read it again for the hand-over
-    for (int k = tid; k < T + 2 * KM; k += NT) { const long long j = (long long)g0 - KM + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
+    {   K kw2[KW];                                   // (all loads in flight together, as in the staging)
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            const int k = tid + q * NT;
+            const long long j = (long long)g0 - KM + k;
+            const bool in = k < T + 2 * KM && j >= 0 && j < (long long)n;
+            kw2[q] = skeys[in ? j : (long long)g0];
+            if (!in) kw2[q] = (K)0;
+        }
+#pragma unroll
+        for (int q = 0; q < KW; ++q) { const int k = tid + q * NT; if (k < T + 2 * KM) s_key[k] = kw2[q]; }
+    }
     __syncthreads();
 #endif
 
