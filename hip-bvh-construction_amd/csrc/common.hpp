@@ -87,6 +87,13 @@ __device__ __forceinline__ void rec_load_agent(const bvh2_node* n, u32& w0, u32&
     w0 = __float_as_uint(q0.x); w1 = __float_as_uint(q0.y);
     b = { q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 }
+// the same load in two steps — request now, wait later — so that other loads can be in flight beside it (k_hploc_ext's work list: records, leaves and the parent's
+// keys are independent).  rec_wait waits for EVERYTHING outstanding (vmcnt(0)); the "+v" operands tie the record's registers to it.
+typedef float rec_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rec_load_agent_issue(const bvh2_node* n, rec_v4f& q0, rec_v4f& q1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1" : "=&v"(q0), "=&v"(q1) : "v"(n) : "memory");
+}
+__device__ __forceinline__ void rec_wait(rec_v4f& q0, rec_v4f& q1) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1) :: "memory"); }
 // box part only (bytes 8..31) of a node whose child links were written earlier: 8-byte + 16-byte write-through stores
 __device__ __forceinline__ void node_box_store_agent(bvh2_node* n, const Box& b) {
     u64* q = reinterpret_cast<u64*>(n);
@@ -250,5 +257,10 @@ template <> struct KeyBits<u64> { static constexpr int value = 96; };
 // is the pair (a, a+1) closer than the pair (b, b+1)?  (both pairs adjacent sorted positions)
 __device__ __forceinline__ bool closer(const u32* __restrict__ k, u32 a, u32 b) { return (aug_key(k, a) ^ aug_key(k, a + 1)) < (aug_key(k, b) ^ aug_key(k, b + 1)); }
 __device__ __forceinline__ bool closer(const u64* __restrict__ k, u32 a, u32 b) { return plen(k[a], a, k[a + 1], a + 1) > plen(k[b], b, k[b + 1], b + 1); }
+// the same question with the four keys already loaded (ka = key[a], ka1 = key[a + 1], ...)
+__device__ __forceinline__ bool closer_keys(u32 ka, u32 ka1, u32 a, u32 kb, u32 kb1, u32 b) {
+    return ((((u64)ka << 32) | a) ^ (((u64)ka1 << 32) | (a + 1u))) < ((((u64)kb << 32) | b) ^ (((u64)kb1 << 32) | (b + 1u)));
+}
+__device__ __forceinline__ bool closer_keys(u64 ka, u64 ka1, u32 a, u64 kb, u64 kb1, u32 b) { return plen(ka, a, ka1, a + 1) > plen(kb, b, kb1, b + 1); }
 
 } // namespace bvh

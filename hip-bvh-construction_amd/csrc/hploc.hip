@@ -1150,9 +1150,11 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     const u32 tL = (u32)__shfl((int)L, hbase), tR = (u32)__shfl((int)R, hbase), tP = (u32)__shfl((int)pc, hbase);
     const int side = __shfl(cw.side, hbase);
     const bool owner = ready && slot == 0;
-    // the owner looks up its parent now: the key loads fly while the task runs
-    u32 q = INV;
-    if (owner && !(L == 0u && R == ni)) q = parent_gap(L, R, ni, [&](u32 a, u32 b) { return closer(skeys, a, b); });
+    // the owner's parent: the four keys that decide it are requested now, beside the work list's loads, and compared behind them (round 4: the parent was looked up on the
+    // spot, the leaves and the records were loaded one after the other — three dependent memory round trips at the start of every pass where one suffices; found in the ISA)
+    const bool interior = owner && L != 0u && R != ni;
+    K pk0 = (K)0, pk1 = (K)0, pk2 = (K)0, pk3 = (K)0;
+    if (interior) { pk0 = skeys[R]; pk1 = skeys[R + 1u]; pk2 = skeys[L - 1u]; pk3 = skeys[L]; }
 
     // work list (loadIndices :192-206): one child may be the half's own survivors of the previous pass
     const bool is_left = slot < 16;
@@ -1162,12 +1164,18 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     const u32 cid = (u32)__shfl((int)cw.id, csrc), crep = (u32)__shfl((int)cw.rep, csrc);
     const Box cb = shfl_box(cw.b, csrc);
     const bool carried = have && ((side == 1 && is_left) || (side == 2 && !is_left));
+    const bool from_rec = have && !carried && c_len > HP_HALF;
+    rec_v4f r0 = { 0.f, 0.f, 0.f, 0.f }, r1 = { 0.f, 0.f, 0.f, 0.f };
+    if (from_rec) rec_load_agent_issue(recs + rec_base(is_left, c_start, tP) + s, r0, r1);      // (requested first: the coherent loads take longest)
     u32 id = INV, rep = INV;
     Box b = box_empty();
     if (carried) { id = cid; rep = crep; b = cb; }
     const bool leaf = have && !carried && c_len <= HP_HALF && s < c_len;
     if (leaf) { rep = c_start + s; id = ni + rep; b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1)); }
-    if (have && !carried && c_len > HP_HALF) rec_load_agent(recs + rec_base(is_left, c_start, tP) + s, id, rep, b);
+    rec_wait(r0, r1);                                                                          // one wait for records, leaves and the parent's keys
+    if (from_rec) { id = __float_as_uint(r0.x); rep = __float_as_uint(r0.y); b = { r0.z, r0.w, r1.x, r1.y, r1.z, r1.w }; }
+    u32 q = INV;
+    if (owner && !(L == 0u && R == ni)) q = L == 0u ? R : R == ni ? L - 1u : (closer_keys(pk0, pk1, R, pk2, pk3, L - 1u) ? R : L - 1u);
     const u32 vb = (u32)(__ballot(id != INV) >> hbase);
     const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb & 0xFFFF0000u);
     HpWork w; w.cnt = nl + nr; w.tL = tL; w.have = have; w.final_ = have && tL == 0 && tR == ni;
