@@ -705,7 +705,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ float2 e_bx[3 * T + 2];               // {lx, ly} | {lz, hx} | {hy, hz} per position; the three planes (T + 1) * 8 bytes apart so that the compiler cannot
                                                      // fuse two plane accesses into one ds_read2(st64)_b64 (8 LDS cycles; two ds_read_b64 take 2 each)
     float2* const e_b0 = e_bx; float2* const e_b1 = e_bx + T + 1; float2* const e_b2 = e_bx + 2 * T + 2;
-    __shared__ u32 m_range[T];                       // per gap (relative): L | R << 16 of a local big node; M_EXT: range leaves the block
+    __shared__ u32 m_range[T];                       // per gap (relative): L | parent side << 15 | R << 16 of a local big node; 0xFFFF in the high half: the range leaves the block
     __shared__ unsigned short s_task[T];             // local big nodes grouped by level; later: the maximal local nodes to publish
     __shared__ u32 s_cnt[NLV], s_off[NLV];
     __shared__ u64 s_lvmask[2];                      // the non-empty levels (bit lv of word lv / 64): the level loop visits only those
@@ -793,7 +793,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     if (dbg == 1) return;
 
     // ---- ranges of the block's gaps, clamped to the window [g0-1, g0+T]; a range touching the window's rim is external
-    constexpr u32 M_EXT = 0xFFFFFFFFu;
+    constexpr u32 M_EXT_TAG = 0xFFFF0000u;          // m_range of an external gap: tag | its contribution (see below)
+    auto m_is_ext = [](u32 w) -> bool { return (w >> 16) == 0xFFFFu; };
     const int jmin = g0 ? (int)g0 - 1 : 0;
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
     auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + KM]; };
@@ -851,9 +852,23 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 while (a < b) { const int mid = (a + b + 1) >> 1; if (inside(mid)) a = mid; else b = mid - 1; }
                 hi = a; }
             const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
-            m_range[k] = ext ? M_EXT : 0u;
+            m_range[k] = 0u;
+            if (ext) {
+                // An external node's own contribution to its dependency word (the hand-over adds it): which children are big — child [L, p] iff leaf p - 16 shares
+                // the prefix, child [p + 1, R] iff leaf p + 17 does — and the far ends of the small ones.  Computed HERE, from the key window (it reaches 18 positions
+                // beyond the tile): the hand-over then needs no key at all, and the lean layout no second read of the window (round 4).
+                auto inside_n = [&](int j) -> bool { return j >= 0 && j < (int)n && inside(j); };
+                const bool lbig = inside_n(p - (int)HP_HALF), rbig = inside_n(p + 1 + (int)HP_HALF);
+                int elo = p, ehi = p + 1;
+                if (!lbig) { for (int t = 8; t > 0; t >>= 1) if (inside_n(elo - t)) elo -= t; }          // L in [p-15, p]
+                if (!rbig) { for (int t = 8; t > 0; t >>= 1) if (inside_n(ehi + t)) ehi += t; }          // R in [p+1, p+16]
+                m_range[k] = M_EXT_TAG | (lbig ? 1u : 0u) | (rbig ? 2u : 0u) | ((u32)(p - elo) << 2) | ((u32)(ehi - (p + 1)) << 6);
+            }
             if (!ext && (u32)(hi - lo + 1) > HP_HALF) {
-                m_range[k] = (u32)(lo - (int)g0) | ((u32)(hi - (int)g0) << 16);
+                // (bit 15: the node's parent is the gap on its LEFT, lo - 1 — findParent (:66-81) on the window's keys; the hand-over publishes the node if that parent is external)
+                const u32 gl = (u32)lo, gr = (u32)hi;
+                const u32 pq = parent_gap(gl, gr, ni, [&](u32 a, u32 b2) { return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b2), b2, wkey((int)b2 + 1), b2 + 1u); });
+                m_range[k] = (u32)(lo - (int)g0) | (pq == gr ? 0u : 0x8000u) | ((u32)(hi - (int)g0) << 16);
 #ifdef ABL_SKIP_ABOVE    // in-situ probe: local nodes of more than ABL_SKIP_ABOVE leaves are not run at all (what would the tile kernel cost without its thin upper levels?)
                 if ((u32)(hi - lo + 1) > (u32)ABL_SKIP_ABOVE) continue;
 #endif
@@ -947,7 +962,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const u32 t = tw + (u32)half;
             const bool have = t < c;
             u32 P = 0, L = 0, R = 0;
-            if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0xFFFFu; R = (rg >> 16) & 0x3FFFu; }
+            if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0x3FFFu; R = (rg >> 16) & 0x3FFFu; }
 #if HPB_DEPS
             {   const u32 need = have ? ((P - L + 1u > HP_HALF ? 1u : 0u) + (R - P > HP_HALF ? 1u : 0u)) : 0u;
                 while (true) {
@@ -988,7 +1003,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                         return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b2), b2, wkey((int)b2 + 1), b2 + 1u); });
                     if (q >= g0 && q - g0 < (u32)T) {
                         const u32 pr = __hip_atomic_load(&m_range[q - g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (pr != M_EXT && pr != 0u) { compiler_fence(); atomicAdd(&m_range[q - g0], 1u << 30); }
+                        if (!m_is_ext(pr) && pr != 0u) { compiler_fence(); atomicAdd(&m_range[q - g0], 1u << 30); }
                     }
                 }
             }
@@ -1005,28 +1020,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __builtin_amdgcn_s_setprio(0);
 #endif
     if (dbg == 3) return;
-#if HPB_LEAN
-    // the rounds' key words overwrote the key window (every thread is past the level loop's last barrier): read it again for the hand-over
-    {   K kw2[KW];                                   // (all loads in flight together, as in the staging)
-#pragma unroll
-        for (int q = 0; q < KW; ++q) {
-            const int k = tid + q * NT;
-            const long long j = (long long)g0 - KM + k;
-            const bool in = k < T + 2 * KM && j >= 0 && j < (long long)n;
-            kw2[q] = skeys[in ? j : (long long)g0];
-            if (!in) kw2[q] = (K)0;
-        }
-#pragma unroll
-        for (int q = 0; q < KW; ++q) { const int k = tid + q * NT; if (k < T + 2 * KM) s_key[k] = kw2[q]; }
-    }
-    __syncthreads();
-#endif
 
-    // ---- hand-over, step 1 (one thread per gap): an external node adds its own contribution — which children are small, and
-    // those children's far ends (child [L,p] is big iff leaf p-16 shares the prefix, child [p+1,R] iff leaf p+17 does);
-    // a maximal local node (parent external) is listed for publication.  (s_task is dead as a task list: every thread is past
-    // the level loop's last barrier.)
-    auto gkey = [&](int j) -> K { return (j >= (int)g0 - KM && j < (int)g0 + T + KM) ? s_key[j - (int)g0 + KM] : skeys[j]; };
+    // ---- hand-over, step 1 (one thread per gap): an external node adds its own contribution (prepared with the ranges: which children are small, and
+    // those children's far ends); a maximal local node (parent external) is listed for publication.  (s_task is dead as a task list: every thread is past
+    // the level loop's last barrier.)  No key is read from here on.
     auto ready_push = [&](u32 pc, u32 L, u32 R) {
         const u32 at = atomicAdd(&s_nready, 1u);
         if (at < HPQ_LOCAL) { r_pc[at] = pc; r_L[at] = L; r_R[at] = R; }
@@ -1037,27 +1034,21 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         const u32 k = (u32)tid + (u32)i * NT;
         const u32 pc = g0 + k;
         if (k < nleaf && pc < ni) {
-            if (m_range[k] == M_EXT) {
-                const int p = (int)pc;
-                const K kp = gkey(p);
-                const int c0 = plen(kp, (u32)p, gkey(p + 1), (u32)p + 1u);
-                auto inside = [&](int j) -> bool { return j >= 0 && j < (int)n && shares_prefix(gkey(j), (u32)j, kp, (u32)p, c0); };
-                const bool lbig = inside(p - (int)HP_HALF), rbig = inside(p + 1 + (int)HP_HALF);
-                int lo = p, hi = p + 1;
-                if (!lbig) { for (int t = 8; t > 0; t >>= 1) if (inside(lo - t)) lo -= t; }          // L in [p-15, p]
-                if (!rbig) { for (int t = 8; t > 0; t >>= 1) if (inside(hi + t)) hi += t; }          // R in [p+1, p+16]
+            const u32 rg = m_range[k];
+            if (m_is_ext(rg)) {
+                const bool lbig = (rg & 1u) != 0u, rbig = (rg & 2u) != 0u;
+                const u32 lo = pc - ((rg >> 2) & 15u), hi = pc + 1u + ((rg >> 6) & 15u);
                 const u32 e = (lbig ? 1u : 0u) + (rbig ? 1u : 0u);
-                if (e == 0u) { if ((u32)(hi - lo + 1) > HP_HALF) ready_push(pc, (u32)lo, (u32)hi); }
+                if (e == 0u) { if (hi - lo + 1u > HP_HALF) ready_push(pc, lo, hi); }
                 else {
                     u32 L, R;
-                    if (dep_arrive(dep, pc, dep_word(3u - e, lbig ? 0u : (u32)lo, rbig ? 0u : (u32)hi), L, R)) ready_push(pc, L, R);
+                    if (dep_arrive(dep, pc, dep_word(3u - e, lbig ? 0u : lo, rbig ? 0u : hi), L, R)) ready_push(pc, L, R);
                 }
-            } else if (m_range[k] != 0u) {           // local big node
-                const u32 rg = m_range[k];
-                const u32 L = g0 + (rg & 0xFFFFu), R = g0 + ((rg >> 16) & 0x3FFFu);         // (bits 30..31: HPB_DEPS arrival count)
-                const u32 q = parent_gap(L, R, ni, [&](u32 a, u32 b) {   // both pairs lie inside the key window
-                    return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b), b, wkey((int)b + 1), b + 1u); });
-                if (q < g0 || m_range[q - g0] == M_EXT) s_task[atomicAdd(&s_npub, 1u)] = (unsigned short)(k | (q == R ? 0u : 0x8000u));
+            } else if (rg != 0u) {                   // local big node
+                const u32 L = g0 + (rg & 0x3FFFu), R = g0 + ((rg >> 16) & 0x3FFFu);         // (bits 30..31: HPB_DEPS arrival count)
+                const bool pleft = (rg & 0x8000u) != 0u;
+                const u32 q = pleft ? L - 1u : R;
+                if (q < g0 || m_is_ext(m_range[q - g0])) s_task[atomicAdd(&s_npub, 1u)] = (unsigned short)(k | (pleft ? 0x8000u : 0u));
             }
         }
     }
@@ -1074,7 +1065,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             if (on) {
                 const u32 tk = s_task[j];
                 const u32 rg = m_range[tk & 0x7FFFu];
-                const u32 Lr = rg & 0xFFFFu; L = g0 + Lr; R = g0 + ((rg >> 16) & 0x3FFFu); right = (tk & 0x8000u) != 0u;
+                const u32 Lr = rg & 0x3FFFu; L = g0 + Lr; R = g0 + ((rg >> 16) & 0x3FFFu); right = (tk & 0x8000u) != 0u;
                 const u32 sp = Lr + (u32)sl;
                 TileList::Tag tg; Box b;
                 tl.load(sp, tg, b);
