@@ -104,13 +104,26 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
     const u32 ni = n - 1;
     const u32 g0 = blockIdx.x * (u32)T, g = g0 + (u32)tid;
     const u32 t_end = (g0 + (u32)T < n) ? g0 + (u32)T : n;            // the tile's leaves: [g0, t_end)
-    for (int k = tid; k < T + 2; k += T) { const long long j = (long long)g0 - 1 + k; s_key[k] = (j >= 0 && j < (long long)n) ? skeys[j] : (K)0; }
+    // the key window (T + 2 keys: two loads per thread) and the leaf's primitive index are requested together, the box behind them: two dependent memory round trips.
+    // (Indices clamped instead of branched around: the loop over the window plus the branch per leaf came out as four — load, wait, load, wait, index, wait, box; round 4, ISA.)
+    constexpr int KW = (T + 2 + T - 1) / T;
+    K kw[KW];
+#pragma unroll
+    for (int q = 0; q < KW; ++q) {
+        const int k = tid + q * T;
+        const long long j = (long long)g0 - 1 + k;
+        const bool in = k < T + 2 && j >= 0 && j < (long long)n;
+        kw[q] = skeys[in ? j : (long long)g0];
+        if (!in) kw[q] = (K)0;
+    }
+    const u32 prim = svals[g < n ? g : ni];
+#pragma unroll
+    for (int q = 0; q < KW; ++q) { const int k = tid + q * T; if (k < T + 2) s_key[k] = kw[q]; }
     s_slot[tid] = 0ull;
     if (KARRAS) s_inv[tid] = 0xFFFFu;
     if (tid == 0) s_nq = 0u;
     Box box = box_empty();
     if (g < n) {
-        const u32 prim = svals[g];
         box = box_gather(boxes + prim);                                     // = bounds of Triangle[prim] (:44), computed once in stage E
         node_store_plain(nodes + ni + g, prim, INV, box);                 // leaf record (:36-45); read again only by later launches
     }

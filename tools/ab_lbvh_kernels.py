@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""LBVH builders: per-kernel event times and the un-profiled wall time per build at the config sizes (library from BVH_MI355X_LIB).  python tools/ab_lbvh_kernels.py"""
+import os, sys, time
+import numpy as np, torch
+torch.cuda.init()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bvh_pkg
+pkg = bvh_pkg.load(); ctx = pkg.Context(0)
+for n, kind in ((262144, "sponza"), (2_000_000, "uniform"), (10_000_000, "uniform")):
+    tris = pkg.meshgen.uniform(n, 1) if kind == "uniform" else pkg.meshgen.sponza_like(n, 3)
+    n = len(tris)
+    d = torch.from_numpy(tris.view(np.uint8).reshape(-1)).cuda()
+    for algo in (pkg.ALGO_SINGLEPASS, pkg.ALGO_TWOPASS):
+        b = pkg.BUILDERS[algo]()
+        for _ in range(5): b.build(ctx, d, on_device=True, n=n)
+        chk = b.checksum()
+        ctx.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): b.build(ctx, d, on_device=True, n=n)
+        ctx.synchronize(); wall = (time.perf_counter() - t0) / 50 * 1e3
+        ctx.set_profiling(2)
+        for _ in range(20): b.build(ctx, d, on_device=True, n=n)
+        kt = ctx.kernel_times(); ctx.set_profiling(0)
+        print(f"{kind} {n} {pkg.ALGO_NAMES[algo]:15s} wall {wall:.4f} ms | " + "  ".join(f"{k} {v[0] / 20:.4f}" for k, v in kt.items() if k.startswith("k_lbvh") or k.startswith("k_karras") or k.startswith("k_refit")) + f"  checksum {chk:016x}", flush=True)
