@@ -332,11 +332,41 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         if (chunk >= chunks) break;
         const long long o = (long long)chunk * PLOC_CHUNK;
         // span entry k <-> list position o - HALO + k   (:232-249)
-        for (int k = tid; k < PL_SPAN; k += PL_BLOCK) {
-            const long long gpos = o - PL_HALO + k;
-            if (gpos >= 0 && gpos < (long long)C) { u32 id; Box b; fetch((size_t)gpos, k >= PL_HALO && k < PL_HALO + PLOC_CHUNK, id, b); lds_set(s, k, id, b); }
-            else s.id[k] = INV;
-            s.nn[k] = ~0ull;
+        {   // All of a thread's span entries are requested before the first is waited for (clamped positions, no branch around the loads): the loop over the span — two
+            // trips for the 1024-thread shape, the second one for the 64 halo entries only — came out as load, wait, load, wait: a second dependent memory round trip
+            // in every iteration's ~10 us, spent by one wave while fifteen wait at the barrier (round 4, found in the ISA).
+            constexpr int SPT = (PL_SPAN + PL_BLOCK - 1) / PL_BLOCK;
+            u32 id_[SPT]; Box b_[SPT]; bool in_[SPT]; u32 prim_[SPT];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int k = tid + q * PL_BLOCK;
+                const long long gpos = o - PL_HALO + k;
+                in_[q] = k < PL_SPAN && gpos >= 0 && gpos < (long long)C;
+                const size_t gc = in_[q] ? (size_t)gpos : (size_t)o;                 // (o < C: the chunk exists)
+                if (FIRST) prim_[q] = svals[gc]; else entry_load(list_in, gc, id_[q], b_[q]);
+            }
+            if (FIRST) {
+#pragma unroll
+                for (int q = 0; q < SPT; ++q) {
+                    const int k = tid + q * PL_BLOCK;
+                    b_[q] = box_gather(boxes + prim_[q]); id_[q] = (u32)(in_[q] ? (size_t)(o - PL_HALO + k) : (size_t)o) + ni;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int k = tid + q * PL_BLOCK;
+                if (k < PL_SPAN) {
+                    if (in_[q]) {
+                        lds_set(s, k, id_[q], b_[q]);
+                        if (FIRST && k >= PL_HALO && k < PL_HALO + PLOC_CHUNK) {      // own = the position belongs to this chunk (not its halo): write the PrimRef
+                            float* f = reinterpret_cast<float*>(leaves + (size_t)(o - PL_HALO + k));
+                            reinterpret_cast<u32*>(f)[0] = prim_[q];
+                            f[1] = b_[q].lx; f[2] = b_[q].ly; f[3] = b_[q].lz; f[4] = b_[q].hx; f[5] = b_[q].hy; f[6] = b_[q].hz;
+                        }
+                    } else s.id[k] = INV;
+                    s.nn[k] = ~0ull;
+                }
+            }
         }
         __syncthreads();
         const int lo = (int)(o - PL_HALO < 0 ? PL_HALO - o : 0);                                   // first valid span entry
