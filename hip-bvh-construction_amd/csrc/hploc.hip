@@ -1309,20 +1309,22 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
 #endif
     if (TICKETS) {
         u32* head = q_count + sub * 32u + 1u;
-        constexpr u32 NO_TICKET = 0xFFFFFFFFu;
-        bool ready = false, dry = false, have_item = false;
-        u32 pc = 0, L = 0, R = 0, tk = NO_TICKET, ipc = 0; u64 irg = 0;
+        // (`pending` says that a ticket is outstanding; the ticket's VALUE — the returning atomic's result — is only looked at under it: testing the value itself at the top of
+        //  every iteration made the wave wait for everything outstanding, the previous pass's write-through node stores included, before it could request the next pass's
+        //  loads — round 4, found in the ISA)
+        bool ready = false, dry = false, have_item = false, pending = false;
+        u32 pc = 0, L = 0, R = 0, tk = 0, ipc = 0; u64 irg = 0;
         ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
         while (true) {
             if (have_item && !ready) { pc = ipc; L = (u32)irg; R = (u32)(irg >> 32); ready = true; have_item = false; }
-            if (tk != NO_TICKET && !have_item) {
+            if (pending && !have_item) {
                 if (tk < total) { const size_t at = (size_t)sub * q_cap + tk; ipc = q_pc[at]; irg = q_rng[at]; have_item = true; }
                 else dry = true;
-                tk = NO_TICKET;
+                pending = false;
             }
-            if ((lane & 31) == 0 && !ready && !have_item && tk == NO_TICKET && !dry) tk = atomicAdd(head, 1u);
+            if ((lane & 31) == 0 && !ready && !have_item && !pending && !dry) { tk = atomicAdd(head, 1u); pending = true; }
             const u64 rm = __ballot(ready);
-            if (!rm) { if (__ballot(tk != NO_TICKET || have_item)) continue; break; }
+            if (!rm) { if (__ballot(pending || have_item)) continue; break; }
             ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], wl, prof EXT_TRACE_PASS);
         }
         return;
