@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
 // External nodes (ranges crossing the tiles of k_hploc_block): the sub-queues hold the nodes whose dependencies were complete
 // when the block kernel ended; every wave takes two at a time and climbs while it keeps completing parents (async_climb).
 #ifndef HPX_OCC
-#define HPX_OCC 4        // waves per SIMD of k_hploc_ext (128 VGPRs).  Round 1: 6 (80 VGPRs; emit 0.97 ms at 10 M vs 1.00 at 7, 1.13 at 8); with ext_pass's carried
+#define HPX_OCC 6        // waves per SIMD of k_hploc_ext (80 VGPRs; round 4, after a pass's loads went out together: 10 M 0.2116 -> 0.2055 ms, 40 M 0.633 -> 0.593, 1 M / 2 M / 5 M unchanged; 7: 0.252, 8: 0.294).  Before: 4 (128 VGPRs).  Round 1: 6 (80 VGPRs; emit 0.97 ms at 10 M vs 1.00 at 7, 1.13 at 8); with ext_pass's carried
                          // survivors the kernel wants more registers: k_hploc_ext at 10 M 0.226 (6) / 0.218 (5) / 0.214 (4) / 0.216 (3) / 0.251 (7) ms, 40 M 0.719 -> 0.669, 1 M unchanged
 #endif
 // TICKETS (inputs >= HPX_TICKETS_MIN_N): a task owner (lanes 0 and 32) that is not climbing takes the next item of its sub-queue
