@@ -124,7 +124,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     __shared__ K s_keys[TILE];
     __shared__ u32 s_vals[TILE];
     __shared__ u64 s_wsum[NW];
-    __shared__ u32 s_tile;
+#ifdef BVH_ABLATION
+    __shared__ u32 s_tile;                           // (ticket order of the measurement build)
+#endif
 #if SORT_EARLY_PUBLISH
     __shared__ u32 s_cnt[RADIX];
 #endif
@@ -150,19 +152,21 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     // tests/test_gpu_round2.py exercises it.
 #ifdef BVH_ABLATION
     if (tid == 0) s_tile = (dbg & 64) ? atomicAdd(tile_counter, 1u) : (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-#else
-    if (tid == 0) s_tile = (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 #endif
     const bool dig = tid < RADIX;                    // this thread speaks for digit `tid`
-    if (dig) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s_whist[w][tid] = 0;
+    // every wave clears ITS row of the per-wave digit counters (the ranking only touches the wave's own row, and a wave's LDS operations execute in order): no barrier
+    // between the clearing and the ranking, and the tile's key loads go out at once (round 4: the tile id used to come through LDS behind a barrier)
+    for (int d = lane; d < RADIX; d += WAVE) s_whist[wave][d] = 0;
 #if SORT_EARLY_PUBLISH
-        s_cnt[tid] = 0;
+    if (dig) s_cnt[tid] = 0;
+    __syncthreads();
 #endif
-    }
+#ifdef BVH_ABLATION
     __syncthreads();
     const u32 tile = s_tile;
+#else
+    const u32 tile = (dbg & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+#endif
     const u32 base = tile * (u32)TILE;
     const u32 valid = min((u32)TILE, n - base);
 
