@@ -668,6 +668,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
                          //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
 #endif
+#ifndef HPB_SEARCH_BOTH
+#define HPB_SEARCH_BOTH 0     // A/B switch (off: 0.5825 vs 0.5870 ms — the pre-loop phases of a tile are not what the kernel waits for, tools/tile_phases.py)
+#endif
 #ifndef HPB_STAGE_SERIAL_GATHER
 #define HPB_STAGE_SERIAL_GATHER 1   // 1: a thread's PER box gathers go out one after the other (0: together — measured slower at 10 M, see the staging)
 #endif
@@ -722,6 +725,16 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
+#ifdef ABL_TILE_PHASES    // measurement build: where a tile spends its life, as thread 0 sees it (clock ticks summed over the tiles into words 4.. of every sub-queue's padded head;
+    __shared__ u64 s_ph[8];                                               // (stamps go straight to LDS: no register lives across the kernel for them)          // tools/tile_phases.py): start, staged, ranges + level sort done, level loop done, hand-over done; barrier waits of the loop
+#define TILE_PHASE(K) do { if (threadIdx.x == 0) s_ph[K] = __builtin_amdgcn_s_memtime(); } while (0)   /* the CU's own shader clock: the chip-wide s_memrealtime serialises (17 stamps per tile tripled the kernel) */
+#else
+#define TILE_PHASE(K) do { } while (0)
+#endif
+    TILE_PHASE(0);
+#ifdef ABL_TILE_PHASES
+    if (threadIdx.x == 0) { s_ph[6] = 0ull; s_ph[7] = 0ull; }
+#endif
     const u32 ni = n - 1;
     const u32 g0 = blockIdx.x * (u32)T;
     const u32 nleaf = (n - g0) < (u32)T ? (n - g0) : (u32)T;
@@ -790,6 +803,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     if (tid < NLV) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; s_ncand = 0u; }
     __syncthreads();
+    TILE_PHASE(1);
     if (dbg == 1) return;
 
     // ---- ranges of the block's gaps, clamped to the window [g0-1, g0+T]; a range touching the window's rim is external
@@ -845,12 +859,25 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             // the positions sharing the node's prefix are contiguous around p: plain binary searches over the window for the two
             // ends (a fixed ~log2(T) probes per side; an exponential search costs the wave its longest lane: ~2x as many)
             int lo = p, hi = p + 1;
+#if HPB_SEARCH_BOTH
+            {   // both ends in the same loop: a step's two probes are independent LDS reads (one round trip instead of two; round 4: 18 -> ~9 dependent reads per gap)
+                int la = jmin, lb = p;                                           // first inside position in [jmin, p]
+                int ha = p + 1, hb = jmax;                                       // last inside position in [p+1, jmax]
+                while (la < lb || ha < hb) {
+                    const int lm = (la + lb) >> 1, hm = (ha + hb + 1) >> 1;
+                    const bool il = inside(lm), ih = inside(hm);
+                    if (la < lb) { if (il) lb = lm; else la = lm + 1; }
+                    if (ha < hb) { if (ih) ha = hm; else hb = hm - 1; }
+                }
+                lo = la; hi = ha; }
+#else
             {   int a = jmin, b = p;                                             // first inside position in [jmin, p]
                 while (a < b) { const int mid = (a + b) >> 1; if (inside(mid)) b = mid; else a = mid + 1; }
                 lo = a; }
             {   int a = p + 1, b = jmax;                                         // last inside position in [p+1, jmax]
                 while (a < b) { const int mid = (a + b + 1) >> 1; if (inside(mid)) a = mid; else b = mid - 1; }
                 hi = a; }
+#endif
             const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
             m_range[k] = 0u;
             if (ext) {
@@ -916,6 +943,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #if HPB_DEPS
     static_assert(!HPB_LEAN, "HPB_DEPS needs the key window during the level loop");
 #endif
+    TILE_PHASE(2);
     if (dbg == 2) return;
 #ifdef BVH_ABLATION       // measurement build: merge tasks run by the tile kernel (word 2 of sub-queue 0's padded head; read through BVH_OPT_DEBUG_TASKS_LOCAL)
     if (tid == 0) { u32 t = 0; for (int lv = 0; lv < NLEV; ++lv) t += s_cnt[lv]; atomicAdd(q_count + 2, t); }
@@ -1010,7 +1038,13 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #endif
         }
 #if !HPB_DEPS
+#if defined(ABL_TILE_PHASES) && ABL_TILE_PHASES >= 2     // (2: also the waits at the levels' barriers — two more stamps per level)
+        const u64 ph_b0 = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        if (threadIdx.x == 0) { s_ph[6] += __builtin_amdgcn_s_memtime() - ph_b0; s_ph[7] += 1ull; }
+#else
+        __syncthreads();
+#endif
 #endif
     }
 #if HPB_DEPS
@@ -1019,6 +1053,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #if HPB_PRIO == 1 || HPB_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
 #endif
+    TILE_PHASE(3);
     if (dbg == 3) return;
 
     // ---- hand-over, step 1 (one thread per gap): an external node adds its own contribution (prepared with the ranges: which children are small, and
@@ -1079,6 +1114,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         }
     }
     __syncthreads();
+    TILE_PHASE(4);
     if (dbg == 4) return;
     // ---- step 3: the block's ready nodes join its sub-queue (one atomic per block)
     const u32 nready = s_nready < HPQ_LOCAL ? s_nready : HPQ_LOCAL;
@@ -1087,6 +1123,15 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         __syncthreads();
         for (u32 i = (u32)tid; i < nready; i += (u32)NT) queue_put(q_pc, q_rng, q_cap, sub, s_qbase + i, r_pc[i], r_L[i], r_R[i]);
     }
+#ifdef ABL_TILE_PHASES
+    TILE_PHASE(5);
+    if (tid == 0) {
+        u32* out = q_count + sub * 32u + 4u;           // (per sub-queue head: 19 532 tiles x 8 atomics on ONE cache line took 1.3 ms)
+        for (int k = 0; k < 5; ++k) atomicAdd(out + k, (u32)(s_ph[k + 1] - s_ph[k]));
+        atomicAdd(out + 8, (u32)s_ph[6]); atomicAdd(out + 9, (u32)s_ph[7]); atomicAdd(out + 10, 1u);
+    }
+#endif
+#undef TILE_PHASE
 }
 
 // One pass of k_hploc_ext.  The wave's two halves are sticky here: half h runs the task its owner lane h * 32 holds (queue items are
@@ -1132,7 +1177,7 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     const u64 tr0 = __builtin_amdgcn_s_memrealtime(); const u32 trL = L, trR = R; u32 tr_rounds = 0;
 #endif
 #ifdef ABL_EXT_TIMING    // measurement build: where a pass spends its cycles and which hand-over it takes (words 3.. of sub-queue 0's padded head; tools/ext_timing.py)
-    const u64 t0 = __builtin_amdgcn_s_memtime();
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef ABL_EXT_STOP_ABOVE   // in-situ probe: nodes of more than n / ABL_EXT_STOP_ABOVE leaves are not run (how much of k_hploc_ext is the chain at the top of the tree?)
     if (ready && (R - L + 1u) > (ni + 1u) / (u32)ABL_EXT_STOP_ABOVE) { ready = false; cw.side = 0; st_agent(dep + pc, 0ull); }
@@ -1177,10 +1222,10 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     w.id = ((u32)slot < w.cnt) ? ti : INV;
 
 #ifdef ABL_EXT_TIMING
-    const u64 t1 = __builtin_amdgcn_s_memtime();
+    const u64 t1 = __builtin_amdgcn_s_memrealtime();
     u32 nrounds = 0;
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, [&]() { ++nrounds; });
-    const u64 t2 = __builtin_amdgcn_s_memtime();
+    const u64 t2 = __builtin_amdgcn_s_memrealtime();
 #elif defined(ABL_EXT_TRACE) && !defined(EXT_TRACE_NOHOOK)
     asm volatile("" : "+v"(w.b.lx), "+v"(w.id));                            // (the list is in registers before the stamp)
     const u64 tr1 = __builtin_amdgcn_s_memrealtime();
@@ -1240,7 +1285,7 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
 #endif
 #endif
 #ifdef ABL_EXT_TIMING
-    {   const u64 t3 = __builtin_amdgcn_s_memtime();
+    {   const u64 t3 = __builtin_amdgcn_s_memrealtime();
         const u64 hm = __ballot(have && slot == 0);
         // per-wave accumulation in the caller's registers (prof points at the wave's 16 counters, lane 0 only)
         if (lane == 0) {
@@ -1297,10 +1342,10 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
 #ifdef ABL_EXT_TIMING
     u32 profw[16] = { 0 };
     u32* const prof = profw;
-    const u64 tw0 = __builtin_amdgcn_s_memtime();
+    const u64 tw0 = __builtin_amdgcn_s_memrealtime();
     // flushed when the wave ends: per-sub-queue copies of the counters (words 3..15 of the sub-queue's padded head) + a histogram of wave lifetimes (words 16..31, 2^15 cycles per bin)
     struct WaveEnd { u32* out; u32* prof; u64 tw0; int lane; __device__ ~WaveEnd() { if (lane == 0) {
-        const u32 life = (u32)(__builtin_amdgcn_s_memtime() - tw0);
+        const u32 life = (u32)(__builtin_amdgcn_s_memrealtime() - tw0);
         for (int k = 0; k < 13; ++k) if (prof[k]) atomicAdd(out + 3 + k, k >= 4 && k <= 6 ? prof[k] >> 6 : prof[k]);
         atomicAdd(out + 3 + 7, life >> 10); atomicAdd(out + 3 + 8, 1u);
         const u32 bin = life >> 15; atomicAdd(out + 16 + (bin < 15u ? bin : 15u), 1u); } } } wave_end{ q_count + sub * 32u, profw, tw0, lane };
