@@ -466,7 +466,13 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
             nbr = (u32)nn_search_wide(b, st, off, a_cnt, ah + slot, slot, lane, nn) & 31u;
         } else
         if (IL) { const u32 p1 = (u32)slot + 1u < nl ? base + (u32)slot + 1u : rbase + (u32)slot + 1u; nbr = (u32)nn_search_il(b, list, p1 < lim ? p1 : lim, act, cnt, slot, nn + hbase) & 31u; }
-        else nbr = (u32)nn_search(b, act, cnt, lane, slot, nn) & 31u;
+        else {
+            const u32 raw = (u32)nn_search(b, act, cnt, lane, slot, nn);
+            nbr = raw & 31u;
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_BPERM)     // (keeps nn_search's in-situ probes alive in the tile kernel: the mask above would let the compiler drop them)
+            if (raw & 64u) cnt = 0u;
+#endif
+        }
         // mergeClusters (:126-190): the neighbour's choice (low word of its key) and its record, read in one go
         const bool in = act && (u32)slot < cnt;
         const u32 pn = nbr < nl ? base + nbr : rbase + nbr;
