@@ -447,6 +447,9 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
     // a task that needs no round only left-packs its right child's clusters (done up front: a helping half's b does not survive the loop, HPB_WIDE)
     if (have && cnt <= threshold && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);
     while (__ballot(have && cnt > threshold)) {
+#if HPB_NO_HOIST
+        asm volatile("" : "+v"(slot));          // the eight `slot + r` of the search are recomputed every round instead of living in eight registers across the loop
+#endif
         const bool act = have && cnt > threshold;
         u32 nbr;
         bool wide = false;
@@ -674,6 +677,9 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
                          //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
 #endif
+#ifndef HPB_NO_HOIST
+#define HPB_NO_HOIST 0       // A/B switch (off).  1: 49 VGPRs instead of 64 (the eight hoisted `slot + r` go), but 0.5873 -> 0.5968 ms: the registers buy nothing while LDS holds the
+#endif                     //    kernel at eight workgroups per CU; with HPB_WIDE on top (58 VGPRs, no spill) 0.5897 — the whole-wave lone rounds give back what the recomputation costs
 #ifndef HPB_SEARCH_BOTH
 #define HPB_SEARCH_BOTH 0     // A/B switch (off: 0.5825 vs 0.5870 ms — the pre-loop phases of a tile are not what the kernel waits for, tools/tile_phases.py)
 #endif
