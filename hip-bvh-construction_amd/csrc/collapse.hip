@@ -31,8 +31,8 @@ constexpr int CL_BLOCK = 256;
 // ids [begin_l, end_l): begin_0 / end_0 come from the host (the root task, or what the previous batch's read-back says), begin_l = end_(l-1),
 // end_l = begin_l + state[l-1] — every count a launch reads was finished by an earlier launch — and it allocates id = end_l + atomicAdd(&state[l], count).
 __global__ void k_collapse_init(uint2* taskq, u32* state, u32 root, int with_root) {
-    if (with_root && threadIdx.x == 0) taskq[0] = make_uint2(root, INV);                      // src/TwoPassLbvh.cpp:160-167
-    for (int i = threadIdx.x; i < COLLAPSE_MAX_BATCH; i += blockDim.x) state[i] = 0u;
+    if (with_root && tid_x() == 0) taskq[0] = make_uint2(root, INV);                      // src/TwoPassLbvh.cpp:160-167
+    for (int i = tid_x(); i < COLLAPSE_MAX_BATCH; i += bdim_x()) state[i] = 0u;
 }
 
 __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __restrict__ nodes, const bvh_primref* __restrict__ leaves,
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __
     const u32 ni = n - 1;
     __shared__ u32 s_base, s_count;
     auto box_of = [&](u32 c) -> Box { return (layout == 1 && c >= ni) ? box_load_u(&leaves[c - ni].aabb) : box_load(&nodes[c].aabb); };
-    for (u32 g0 = begin + blockIdx.x * CL_BLOCK; g0 < end; g0 += gridDim.x * CL_BLOCK) {     // block-uniform
-        const u32 g = g0 + threadIdx.x;
+    for (u32 g0 = begin + bid_x() * CL_BLOCK; g0 < end; g0 += nbid_x() * CL_BLOCK) {     // block-uniform
+        const u32 g = g0 + tid_x();
         const bool have = g < end;
         u32 ci[4] = { INV, INV, INV, INV }; Box cb[4]; u32 cc = 0, parent = INV, n_int = 0;
         if (have) {
@@ -74,12 +74,12 @@ __global__ __launch_bounds__(CL_BLOCK) void k_collapse_level(const bvh2_node* __
         }
         // block-aggregated allocation of the internal children's wide ids
         __syncthreads();
-        if (threadIdx.x == 0) s_count = 0;
+        if (tid_x() == 0) s_count = 0;
         __syncthreads();
         u32 my_off = 0;
         if (n_int) my_off = atomicAdd(&s_count, n_int);
         __syncthreads();
-        if (threadIdx.x == 0) s_base = s_count ? end + atomicAdd(alloc, s_count) : 0u;
+        if (tid_x() == 0) s_base = s_count ? end + atomicAdd(alloc, s_count) : 0u;
         __syncthreads();
         if (have) {
             Wide4 w;

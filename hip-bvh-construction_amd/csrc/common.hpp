@@ -36,6 +36,15 @@ __device__ __forceinline__ void st_agent(u32* p, u32 v) { __hip_atomic_store(p, 
 __device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+// Work-item / workgroup ids as compiler builtins.  The emit kernels are compiled with -mno-amdgpu-ieee; threadIdx / blockIdx / gridDim go through
+// __ockl_get_local_id & co., device-library functions compiled WITH the IEEE mode, which the inliner then refuses to inline: every kernel started with
+// two or three real function calls (s_swappc), 64-bit ids of unknown range and a 32-VGPR floor.  The builtins carry the launch bounds' ranges.
+__device__ __forceinline__ u32 tid_x() { return __builtin_amdgcn_workitem_id_x(); }
+__device__ __forceinline__ u32 bid_x() { return __builtin_amdgcn_workgroup_id_x(); }
+__device__ __forceinline__ u32 bdim_x() { return __builtin_amdgcn_workgroup_size_x(); }
+// workgroups of the launch: hidden_block_count_x, the first word of the implicit kernel arguments (code object v5: what __ockl_get_num_groups(0) reads).  Not
+// __builtin_amdgcn_grid_size_x(): that one loads from the AQL dispatch packet — host memory, a microsecond per wave (measured: PLOC++ at 262 144 0.39 -> 0.48 ms).
+__device__ __forceinline__ u32 nbid_x() { return ((const u32*)__builtin_amdgcn_implicitarg_ptr())[0]; }
 
 __device__ __forceinline__ u64 pack2(float a, float b) { return (u64)__float_as_uint(a) | ((u64)__float_as_uint(b) << 32); }
 __device__ __forceinline__ float lo_f(u64 v) { return __uint_as_float((u32)v); }

@@ -128,20 +128,32 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
                            //    no longer spills at 7 waves per SIMD) and each pair's atomics leave as soon as its area exists: tile kernel 0.714 -> 0.67 ms; 0: two per step, packed f32
 #endif
 #ifndef HP_NN_LDS
-#define HP_NN_LDS 1        // 1: neighbour selection by LDS atomic minima (default); 0: round 1's alternative (two running minima in registers, the left
-#endif                     //    candidates' areas through ds_bpermute; needs more registers: spills at 7 waves per SIMD) for A/B builds
+#define HP_NN_LDS 3        // neighbour selection.  3 (default since round 4): the pair's key is minimised into the FAR end's word by an LDS atomic (the reference's formulation) and into
+                           //    the lane's own running minimum by ONE v_min_f64 on the same 64-bit key (eight LDS atomics per round instead of sixteen; k_hploc_ext 0.200 -> 0.195 ms,
+                           //    tile kernel unchanged; needs -fno-slp-vectorize, see the Makefile); 1: both ends by LDS atomics (rounds 1-4); 2: own end as a compare-select chain
+                           //    on {area, slot} (measured slower); 0: round 1's alternative (two running minima in registers, the left candidates' areas through ds_bpermute)
+#endif
 // findNearestNeighbours (:83-117) of one PLOC round for the two tasks of a wave: every pair (slot, slot + r), r = 1..8, is evaluated ONCE, by its
 // lower end — neighbour boxes arrive through a DPP wave_shl:1 chain, two candidates per step so that the area arithmetic runs as packed f32 (same
 // operations, same association, no contraction; the min / max of the unions have no packed form) — and its 64-bit key {area bits, other end's slot} is
-// minimised into BOTH ends' words with LDS atomics (ds_min_u64: the reference's formulation; a wave's LDS operations execute in order, so the reset,
-// the atomics and the read-back need no barrier).  Returns the slot of the lane's nearest neighbour (lowest slot on equal areas).
+// minimised into BOTH ends: the far end's word with an LDS atomic (ds_min_u64: the reference's formulation; a wave's LDS operations execute in order, so the reset,
+// the atomics and the read-back need no barrier), the lane's own minimum in a register pair (HP_NN_LDS = 3; = 1: an LDS atomic too).  Returns the slot of the
+// lane's nearest neighbour (lowest slot on equal areas).  PUBLISH: the choice is also left in the low half of the lane's key word (ploc_rounds_lds reads it there).
 // nn: the wave's 64-entry LDS scratch.  ABL_*: in-situ cost probes of tools/ab_probe.sh (wrong trees, timing only; profiles/r03_hploc_bound.md).
+template <bool PUBLISH = false>
 __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int lane, int slot, u64* nn) {
 #if HP_NN_LDS
     nn[lane] = ~0ull;
     compiler_fence();                        // reset, atomics and read-back stay in program order
 #if HP_NN_LDS == 2
     u32 abR = 0xFFFFFFFFu; int idR = 0;      // the lane's own right-hand candidates: running minimum in registers (strict <: lowest slot on equal areas)
+#endif
+#if HP_NN_LDS == 3
+    // the lane's own right-hand candidates: the SAME 64-bit key {area bits, other end's slot}, minimised in a register pair by v_min_f64 — one VALU instruction
+    // instead of one LDS atomic.  An area is a non-negative f32, so the key read as an f64 is a non-negative finite number (its exponent field is the area's
+    // sign, exponent and three mantissa bits: never all ones), and non-negative doubles order like their bit patterns; f64 denormals (areas below 2^-126) are
+    // compared, not flushed (the f64 denormal mode of every HIP kernel is "preserve"), and a minimum returns one of its operands bit for bit.
+    double own = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
 #endif
 #else
     // two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the lower slot on ties), left
@@ -165,6 +177,8 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
             atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
 #if HP_NN_LDS == 2
             if (ab < abR) { abR = ab; idR = slot + rr; }
+#elif HP_NN_LDS == 3
+            own = __builtin_fmin(own, __longlong_as_double((long long)(((unsigned long long)ab << 32) | (u32)(slot + rr))));
 #else
             atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
 #endif
@@ -233,6 +247,16 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
     compiler_fence();
     const u64 left = nn[lane];               // minimum over the pairs (slot - r, slot): lower slots, so it wins on equal areas
     return ((u32)(left >> 32) <= abR ? (int)(u32)left : idR) | (probe == 0x7fffabcd ? 64 : 0);
+#elif HP_NN_LDS == 3
+    compiler_fence();
+    const u64 left = nn[lane];               // minimum over the pairs (slot - r, slot), or all ones
+    const u64 right = (u64)__double_as_longlong(own);
+    const u32 choice = (u32)(left < right ? left : right);
+    if (PUBLISH) {                           // (ploc_rounds_lds reads the neighbour's choice from the low half of its key word)
+        reinterpret_cast<u32*>(nn + lane)[0] = choice;
+        compiler_fence();
+    }
+    return (int)choice | (probe == 0x7fffabcd ? 64 : 0);
 #else
     return ((abL <= abR) ? idL : idR) | (probe == 0x7fffabcd ? 64 : 0);
 #endif
@@ -308,6 +332,9 @@ __device__ __forceinline__ int nn_search_il(const Box& b, const List& list, u32 
 // nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (nn_search)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // hook: called at the end of every round (the measurement builds count rounds there; tools/probes/hploc_ext_lookahead_wide.patch consumed an early load)
+#ifndef HPX_NO_HOIST
+#define HPX_NO_HOIST 0
+#endif
 template <bool AGENT = true, typename Hook = NoHook>
 __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, u64* nn, Hook hook = Hook()) {
         const bool have = w.have, final_ = w.final_;
@@ -315,6 +342,9 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
         Box b = w.b;
         const u32 threshold = final_ ? 1u : HP_HALF;
         while (__ballot(have && cnt > threshold)) {
+#if HPX_NO_HOIST
+            asm volatile("" : "+v"(slot));      // the eight `slot + r` of the search are recomputed every round instead of living in eight registers across the kernel's loop
+#endif
             const bool act = have && cnt > threshold;
             const int nbr = nn_search(b, act, cnt, lane, slot, nn);
             // mergeClusters (:126-190)
@@ -470,7 +500,7 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
         } else
         if (IL) { const u32 p1 = (u32)slot + 1u < nl ? base + (u32)slot + 1u : rbase + (u32)slot + 1u; nbr = (u32)nn_search_il(b, list, p1 < lim ? p1 : lim, act, cnt, slot, nn + hbase) & 31u; }
         else {
-            const u32 raw = (u32)nn_search(b, act, cnt, lane, slot, nn);
+            const u32 raw = (u32)nn_search<true>(b, act, cnt, lane, slot, nn);
             nbr = raw & 31u;
 #if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_BPERM)     // (keeps nn_search's in-situ probes alive in the tile kernel: the mask above would let the compiler drop them)
             if (raw & 64u) cnt = 0u;
@@ -479,7 +509,7 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
         // mergeClusters (:126-190): the neighbour's choice (low word of its key) and its record, read in one go
         const bool in = act && (u32)slot < cnt;
         const u32 pn = nbr < nl ? base + nbr : rbase + nbr;
-#if HP_NN_LDS == 1
+#if HP_NN_LDS == 1 || HP_NN_LDS == 3
         const u32 nbr_of_nbr = (u32)nn[hbase + (int)nbr];              // (the key word's low half IS the neighbour's choice)
 #else
         const u32 nbr_of_nbr = (u32)__shfl((int)nbr, hbase + (int)nbr);
@@ -594,18 +624,18 @@ template <typename K>
 __global__ __launch_bounds__(HP_BLOCK, HPA_OCC) void k_hploc(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* leaves,
                                                     bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 n, int dbg) {
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = tid_x() & (WAVE - 1);
     const u32 ni = n - 1;
-    u32 pc = blockIdx.x * HP_BLOCK + threadIdx.x;      // LBVH gap / node this lane currently speaks for
+    u32 pc = bid_x() * HP_BLOCK + tid_x();      // LBVH gap / node this lane currently speaks for
     u32 L = 0, R = 0;
     bool ready = false;
 
     // The block's key window [g0 - 256, g0 + 512] sits in LDS: almost every probe of the common-prefix searches lands there
     // (a dependent L2 round trip per probe otherwise); only ranges reaching beyond the window probe global memory.
     __shared__ K s_keys[HP_BLOCK * 3 + 1];
-    const int g0 = (int)(blockIdx.x * HP_BLOCK);
+    const int g0 = (int)(bid_x() * HP_BLOCK);
     const int w0 = g0 - HP_BLOCK;
-    for (int k = threadIdx.x; k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : (K)0; }
+    for (int k = tid_x(); k < HP_BLOCK * 3 + 1; k += HP_BLOCK) { const int j = w0 + k; s_keys[k] = (j >= 0 && j < (int)n) ? skeys[j] : (K)0; }
     __syncthreads();
     auto key_at = [&](int j) -> K { return ((u32)(j - w0) <= (u32)(HP_BLOCK * 3)) ? s_keys[j - w0] : skeys[j]; };
     if (pc < ni) {
@@ -637,7 +667,7 @@ __global__ __launch_bounds__(HP_BLOCK, HPA_OCC) void k_hploc(const bvh_aabb* __r
     }
     if (dbg == 1) return;
     __shared__ u64 s_nn[HP_BLOCK / WAVE][WAVE];
-    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, ni, lane, s_nn[threadIdx.x / WAVE]);
+    async_climb<true>(ready, pc, L, R, boxes, skeys, svals, leaves, nodes, recs, dep, zero_parent, ni, lane, s_nn[tid_x() / WAVE]);
 }
 
 // =====================================================================================================================
@@ -732,25 +762,25 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #endif
 #ifdef ABL_LDS_PAD       // in-situ probe: fewer workgroups per CU (is the kernel bound by latency x occupancy?)
     __shared__ u32 s_pad[ABL_LDS_PAD / 4];
-    if (threadIdx.x == 0 && n == 0xFFFFFFFFu) s_pad[blockIdx.x % (ABL_LDS_PAD / 4)] = 1u;
+    if (tid_x() == 0 && n == 0xFFFFFFFFu) s_pad[bid_x() % (ABL_LDS_PAD / 4)] = 1u;
 #endif
 
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int tid = tid_x(), lane = tid & (WAVE - 1), wave = tid >> 6;
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
 #ifdef ABL_TILE_PHASES    // measurement build: where a tile spends its life, as thread 0 sees it (clock ticks summed over the tiles into words 4.. of every sub-queue's padded head;
     __shared__ u64 s_ph[8];                                               // (stamps go straight to LDS: no register lives across the kernel for them)          // tools/tile_phases.py): start, staged, ranges + level sort done, level loop done, hand-over done; barrier waits of the loop
-#define TILE_PHASE(K) do { if (threadIdx.x == 0) s_ph[K] = __builtin_amdgcn_s_memtime(); } while (0)   /* the CU's own shader clock: the chip-wide s_memrealtime serialises (17 stamps per tile tripled the kernel) */
+#define TILE_PHASE(K) do { if (tid_x() == 0) s_ph[K] = __builtin_amdgcn_s_memtime(); } while (0)   /* the CU's own shader clock: the chip-wide s_memrealtime serialises (17 stamps per tile tripled the kernel) */
 #else
 #define TILE_PHASE(K) do { } while (0)
 #endif
     TILE_PHASE(0);
 #ifdef ABL_TILE_PHASES
-    if (threadIdx.x == 0) { s_ph[6] = 0ull; s_ph[7] = 0ull; }
+    if (tid_x() == 0) { s_ph[6] = 0ull; s_ph[7] = 0ull; }
 #endif
     const u32 ni = n - 1;
-    const u32 g0 = blockIdx.x * (u32)T;
+    const u32 g0 = bid_x() * (u32)T;
     const u32 nleaf = (n - g0) < (u32)T ? (n - g0) : (u32)T;
-    const u32 sub = blockIdx.x % HPQ_SUB;
+    const u32 sub = bid_x() % HPQ_SUB;
     const TileList tl{ e_ir, e_b0, e_b1, e_b2, g0, ni };
 
 #if HPB_PRIO == 3
@@ -974,7 +1004,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    shows the hardware starts every workgroup's round-robin on the next SIMD (wave 0 lands on each SIMD a quarter of the time) — and the
                          //    switch changes nothing (0.6500 / 0.6515 vs 0.6511 / 0.6495 ms).  Off.
 #if HPB_ROT
-    const u32 wrot = ((u32)wave + blockIdx.x) & (u32)(NW - 1);
+    const u32 wrot = ((u32)wave + bid_x()) & (u32)(NW - 1);
 #else
     const u32 wrot = (u32)wave;
 #endif
@@ -1053,7 +1083,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #if defined(ABL_TILE_PHASES) && ABL_TILE_PHASES >= 2     // (2: also the waits at the levels' barriers — two more stamps per level)
         const u64 ph_b0 = __builtin_amdgcn_s_memtime();
         __syncthreads();
-        if (threadIdx.x == 0) { s_ph[6] += __builtin_amdgcn_s_memtime() - ph_b0; s_ph[7] += 1ull; }
+        if (tid_x() == 0) { s_ph[6] += __builtin_amdgcn_s_memtime() - ph_b0; s_ph[7] += 1ull; }
 #else
         __syncthreads();
 #endif
@@ -1330,17 +1360,17 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
                                                    bvh2_node* recs, u64* dep, u32* zero_parent,
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, u32* q_count, u32 q_cap, u32 n) {
     __shared__ u64 s_nn[256 / WAVE][WAVE];
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = tid_x() & (WAVE - 1);
 #if HPX_LDS_LIST          // (A/B switch, off: the per-wave work lists of that variant — 8 KB of LDS the default kernel does not reserve)
     __shared__ u64 s_lir[256 / WAVE][WAVE];
     __shared__ float2 s_lb[3][256 / WAVE][WAVE + 1];
-    const int wv = threadIdx.x / WAVE;
+    const int wv = tid_x() / WAVE;
     const WaveList wl{ s_lir[wv], s_lb[0][wv], s_lb[1][wv], s_lb[2][wv] };
 #else
     const WaveList wl{ nullptr, nullptr, nullptr, nullptr };
 #endif
-    const u32 nwaves = gridDim.x * (256 / WAVE);
-    const u32 wid = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const u32 nwaves = nbid_x() * (256 / WAVE);
+    const u32 wid = bid_x() * (256 / WAVE) + (tid_x() >> 6);
     const u32 sub = wid % HPQ_SUB;                                       // (nwaves is a multiple of HPQ_SUB)
     const u32 total = q_count[sub * 32u];
 #ifdef ABL_EXT_TRACE
@@ -1382,7 +1412,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
             if ((lane & 31) == 0 && !ready && !have_item && !pending && !dry) { tk = atomicAdd(head, 1u); pending = true; }
             const u64 rm = __ballot(ready);
             if (!rm) { if (__ballot(pending || have_item)) continue; break; }
-            ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], wl, prof EXT_TRACE_PASS);
+            ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl, prof EXT_TRACE_PASS);
         }
         return;
     }
@@ -1393,7 +1423,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         u32 pc = 0, L = 0, R = 0;
         if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
         ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
-        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[threadIdx.x / WAVE], wl, prof EXT_TRACE_PASS);
+        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl, prof EXT_TRACE_PASS);
     }
 }
 

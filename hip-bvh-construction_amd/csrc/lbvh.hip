@@ -72,7 +72,7 @@ template <typename K>
 __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_single(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                             const u32* __restrict__ svals, bvh2_node* nodes, u64* slots,
                                                             u32* root_out, u32 n) {
-    const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
+    const u32 g = bid_x() * LBVH_BLOCK + tid_x();
     if (g >= n) return;
     const u32 ni = n - 1;
     const u32 prim = svals[g];
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
     __shared__ u64 s_q[T];                           // subtree roots handed to k_lbvh_ext: {node : 32 | i - g0 : 16 | j - g0 : 16}
     __shared__ unsigned short s_inv[KARRAS ? T : 1]; // Karras numbering: node index - g0 -> gap whose node carries it (0xFFFF: none in this tile)
     __shared__ u32 s_nq;
-    const int tid = threadIdx.x;
+    const int tid = tid_x();
     const u32 ni = n - 1;
-    const u32 g0 = blockIdx.x * (u32)T, g = g0 + (u32)tid;
+    const u32 g0 = bid_x() * (u32)T, g = g0 + (u32)tid;
     const u32 t_end = (g0 + (u32)T < n) ? g0 + (u32)T : n;            // the tile's leaves: [g0, t_end)
     // the key window (T + 2 keys: two loads per thread) and the leaf's primitive index are requested together, the box behind them: two dependent memory round trips.
     // (Indices clamped instead of branched around: the loop over the window plus the branch per leaf came out as four — load, wait, load, wait, index, wait, box; round 4, ISA.)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(T) void k_lbvh_block(const bvh_aabb* __restrict__ b
     // the tile's roots go to the tile's own segment of the queue (T entries; entry 0 carries the count in .w): no atomic, no round trip at the
     // end of the workgroup (a returning atomic on a sub-queue head here was ~2 us of a ~20 us workgroup)
     const u32 nq = s_nq;
-    uint4* seg = queue + (size_t)blockIdx.x * (size_t)T;
+    uint4* seg = queue + (size_t)bid_x() * (size_t)T;
     if (tid == 0 && nq == 0u) seg[0] = make_uint4(0u, 0u, 0u, 0u);
     for (u32 k = (u32)tid; k < nq; k += (u32)T) {
         const u64 it = s_q[k];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_lbvh_ext(const K* __restrict__ s
     // the chip holds), at 2 M 0.062 / 0.048 / 0.042.
     const u32 ntiles = (n + (u32)LBVH_TILE - 1u) / (u32)LBVH_TILE;
     const u32 lanes = 1u << slot_shift;
-    for (u32 idx = blockIdx.x * LBVH_BLOCK + threadIdx.x; idx < (ntiles << slot_shift); idx += gridDim.x * LBVH_BLOCK) {
+    for (u32 idx = bid_x() * LBVH_BLOCK + tid_x(); idx < (ntiles << slot_shift); idx += nbid_x() * LBVH_BLOCK) {
         const uint4* seg = queue + (size_t)(idx >> slot_shift) * (size_t)LBVH_TILE;
         const u32 cnt = seg[0].w;
         for (u32 k = idx & (lanes - 1u); k < cnt; k += lanes) {
@@ -229,15 +229,15 @@ __global__ __launch_bounds__(LBVH_BLOCK) void k_karras(const bvh_aabb* __restric
                                                        const u32* __restrict__ svals, bvh2_node* __restrict__ nodes,
                                                        u32* __restrict__ parent, u32 n) {
     __shared__ K s_keys[LBVH_BLOCK * 3 + 1];
-    const int g0 = (int)(blockIdx.x * LBVH_BLOCK), w0 = g0 - LBVH_BLOCK;
-    for (int t = threadIdx.x; t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : (K)0; }
+    const int g0 = (int)(bid_x() * LBVH_BLOCK), w0 = g0 - LBVH_BLOCK;
+    for (int t = tid_x(); t < LBVH_BLOCK * 3 + 1; t += LBVH_BLOCK) { const int j = w0 + t; s_keys[t] = (j >= 0 && j < (int)n) ? k[j] : (K)0; }
     __syncthreads();
     auto key_at = [&](u32 j) -> K { return ((u32)((int)j - w0) <= (u32)(LBVH_BLOCK * 3)) ? s_keys[(int)j - w0] : k[j]; };
     auto delta2p = [&](u32 i, u32 j) -> int {                  // countCommonPrefixBits as used at :52-54 (u32: 32 + clz(i^j) / clz(a^b))
         const K a = key_at(i), b = key_at(j);
         return (a == b) ? ((int)sizeof(K) * 8 + clz_u32(i ^ j)) : (sizeof(K) == 4 ? clz_u32((u32)(a ^ b)) : clz_u64((u64)(a ^ b)));
     };
-    const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
+    const u32 g = bid_x() * LBVH_BLOCK + tid_x();
     if (g >= n) return;
     const u32 ni = n - 1;
     {   // InitBvhNodesPrimRef (:164-194): leaf = {primRef.primIdx, INVALID, primRef.aabb}; PrimRef i = {i, bounds(tri i)}
@@ -293,7 +293,7 @@ __device__ __forceinline__ void refit_climb(u32 cur, Box box, bvh2_node* nodes, 
 }
 
 __global__ __launch_bounds__(LBVH_BLOCK) void k_refit(bvh2_node* nodes, const u32* __restrict__ parent, u32* flags, u32 n) {
-    const u32 g = blockIdx.x * LBVH_BLOCK + threadIdx.x;
+    const u32 g = bid_x() * LBVH_BLOCK + tid_x();
     if (g >= n) return;
     const u32 cur = n - 1 + g;
     refit_climb(cur, box_load(&nodes[cur].aabb), nodes, parent, flags);    // leaf box: written by k_karras (previous launch)

@@ -85,7 +85,7 @@ __device__ __forceinline__ u32 nearest(const PlocLds& s, int k, int lo, int hi) 
 // block-wide exclusive scan of a packed {merges<<16 | kept} per-thread count; returns exclusive prefix, total via *total
 template <int PL_BLOCK>
 __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int lane = tid_x() & (WAVE - 1), wave = tid_x() / WAVE;
     u32 inc = v;
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) { const u32 t = (u32)__shfl_up((int)inc, off); if (lane >= off) inc += t; }
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
     constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
     __shared__ PlocLds s;
     const u32 C = counts[0];
-    if (C <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = C; return; }
-    const int tid = threadIdx.x;
+    if (C <= 1) { if (bid_x() == 0 && tid_x() == 0) counts[1] = C; return; }
+    const int tid = tid_x();
     // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
     auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
         if (FIRST) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
     auto nn_pairs = [&](const int lo, const int hi) { nn_pairs_fn<PL_BLOCK>(s, tid, lo, hi); };
     if (C < (u32)PLOC_CHUNK) {
         // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
-        if (blockIdx.x != 0) return;
+        if (bid_x() != 0) return;
         for (int k = tid; k < (int)C; k += PL_BLOCK) { u32 id; Box b; fetch((size_t)k, true, id, b); lds_set(s, k, id, b); }
         __syncthreads();
         u32 c = C;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         // `chunks` different workgroups, so nobody needs to ask again just to learn that the list is used up — the finish below starts a round trip earlier
         // Measured on the MI355X (whole build, same box): Sponza-like 262 144 0.4107 -> 0.4065 ms, 524 288 0.5216 -> 0.5180, uniform 1 M 0.5630 -> 0.5605; but 2 M
         // 0.783 -> 0.790 and 10 M 2.206 -> 2.245 (there the second ticket's round trip is what gives the predecessors time to publish before the walk): small inputs only
-        if (gridDim.x >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;              // (grid-uniform)
+        if (nbid_x() >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;              // (grid-uniform)
 #endif
     }
 #if PLOC_DEFER
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(PLOC_CHUNK, 1) void k_ploc_resident(PlocXchg* xchg,
                                                                 const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
     __shared__ PlocLds s;
     __shared__ u32 s_red[8];               // [0] merges before this part, [1] all merges, [2] kept before, [3] smallest part, [4] merges of the left neighbour
-    const int tid = threadIdx.x;
-    const u32 w = blockIdx.x, G = gridDim.x, ni = n - 1u;
+    const int tid = tid_x();
+    const u32 w = bid_x(), G = nbid_x(), ni = n - 1u;
     u32 C = n;
     u32 m = n - w * (u32)PLOC_CHUNK < (u32)PLOC_CHUNK ? n - w * (u32)PLOC_CHUNK : (u32)PLOC_CHUNK;       // this part: span entries [HALO, HALO + m)
     // the first list is the sorted leaves themselves (SetupClusters :39-55 fused): part + halos straight from the boxes
@@ -564,7 +564,7 @@ bool ploc_resident(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nod
 
 // one launch clears the per-iteration bookkeeping (two memsets + a one-thread kernel before: three launch boundaries of ~2 us in front of every build)
 __global__ __launch_bounds__(256) void k_ploc_init(u32* __restrict__ state, u32 count, uint4* __restrict__ status, u32 status_vecs, u64* __restrict__ status_tail, u32 tail_words) {
-    const u32 t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    const u32 t = bid_x() * 256 + tid_x(), stride = nbid_x() * 256;
     for (u32 i = t; i < status_vecs; i += stride) status[i] = make_uint4(0u, 0u, 0u, 0u);
     if (t < tail_words) status_tail[t] = 0ull;
     if (t < (u32)PLOC_STATE_WORDS) state[t] = t == 0u ? count : 0u;

@@ -231,7 +231,7 @@ def test_every_small_size(pkg, orc, ctx, mode, sched_opts):
 
 
 @pytest.mark.parametrize("sched", ["default", "block"])
-@pytest.mark.parametrize("kind", ["identical", "two_far_clusters", "line", "point_cloud_dups", "huge_and_tiny", "staircase"])
+@pytest.mark.parametrize("kind", ["identical", "two_far_clusters", "line", "point_cloud_dups", "huge_and_tiny", "staircase", "denormal_areas"])
 @pytest.mark.parametrize("algo", [0, 1, 2, 3])
 def test_degenerate_distributions(pkg, orc, ctx, kind, algo, sched, sched_opts):
     if sched == "block":
@@ -254,6 +254,10 @@ def test_degenerate_distributions(pkg, orc, ctx, kind, algo, sched, sched_opts):
         x = (np.float32(2.0) ** (-(np.arange(6000) % 120).astype(np.float32) / 4)) + (np.arange(6000) // 120).astype(np.float32) * np.float32(1e-6)
         for v in ("v1", "v2", "v3"):
             tris[v][:, 0] = x; tris[v][:, 1] = 0.0; tris[v][:, 2] = 0.0
+    elif kind == "denormal_areas":     # coordinates ~1e-20: every union's area is an f32 denormal (~1e-40) — as the high word of the 64-bit selection key that is an f64
+        tris = mg.uniform(4000, 10)    # denormal too, which the register half of the neighbour selection (v_min_f64, HP_NN_LDS = 3) must compare, not flush
+        for v in ("v1", "v2", "v3"):
+            tris[v] *= np.float32(2.0 ** -66)
     else:                              # one scene-sized triangle among tiny ones (Sponza-like size variance)
         tris = mg.uniform(4000, 8); tris["v1"][0] = (-50, -50, -50); tris["v2"][0] = (60, 0, 0); tris["v3"][0] = (0, 70, 55)
     tris = np.ascontiguousarray(tris); n = len(tris)
