@@ -22,6 +22,9 @@ namespace bvh {
 #ifndef PLOC_DEFER
 #define PLOC_DEFER 1     // 0: walk and store right away (measured at 10 M: emit 2.42 ms instead of 2.00, 2 M: 0.79 instead of 0.75)
 #endif
+#ifndef PLOC_NN_OWN_F64
+#define PLOC_NN_OWN_F64 1   // 1 (round 4): nn_pairs keeps an entry's own candidates in registers (v_min_f64 on the 64-bit key) and sends one atomic per entry; 0: both ends of every pair by LDS atomics
+#endif
 #ifndef PLOC_TAIL_PAIRS
 #define PLOC_TAIL_PAIRS 1
 #endif
@@ -108,6 +111,7 @@ __device__ __forceinline__ u32 block_scan(PlocLds& s, u32 v, u32* total) {
 // Round 3, measured at Sponza-262 144: tail launch 75 -> 58 us, emit 0.383 -> 0.366 ms.  (Also tried: late launches with LDS for 4096 clusters so that the
 // single-workgroup tail starts below 4096 instead of 1024 — the ten 8-us launches it replaces become six in-LDS rounds of ~5 us on ONE CU plus more empty
 // launches at the end of the batch: 0.386 ms, dropped.)
+template <bool OWN>      // OWN: the lane's own candidates (lane, lane + r) in a register pair, v_min_f64 on the 64-bit key (nn_pairs_fn)
 __device__ __forceinline__ void ploc_tail_wave(PlocLds& s, u32 c, bvh2_node* __restrict__ nodes, int lane) {
     u32 id = (u32)lane < c ? s.id[lane] : INV;
     Box b = (u32)lane < c ? lds_box(s, lane) : box_empty();
@@ -116,18 +120,21 @@ __device__ __forceinline__ void ploc_tail_wave(PlocLds& s, u32 c, bvh2_node* __r
         s.nn[lane] = ~0ull; s.nn[lane + WAVE] = ~0ull;     // (pairs reach at most 8 positions beyond the last lane)
         compiler_fence();
         Box nb = b;
+        double own = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
 #pragma unroll
         for (int r = 1; r <= PL_RADIUS; ++r) {
             nb = box_shl1(nb);                             // box of position lane + r
             if ((u32)(lane + r) < c) {
                 const unsigned long long key = (unsigned long long)__float_as_uint(box_area(box_union(nb, b))) << 32;
                 atomicMin(reinterpret_cast<unsigned long long*>(s.nn + lane + r), key | (u32)lane);
-                atomicMin(reinterpret_cast<unsigned long long*>(s.nn + lane), key | (u32)(lane + r));
+                if constexpr (OWN) own = __builtin_fmin(own, __longlong_as_double((long long)(key | (u32)(lane + r))));
+                else atomicMin(reinterpret_cast<unsigned long long*>(s.nn + lane), key | (u32)(lane + r));
             }
         }
         compiler_fence();
         const bool in = (u32)lane < c;
-        const int nbr = in ? (int)(u32)s.nn[lane] : lane;
+        const u64 left = s.nn[lane], right = OWN ? (u64)__double_as_longlong(own) : ~0ull;
+        const int nbr = in ? (int)(u32)(left < right ? left : right) : lane;
         const bool mutual = in && (u32)__shfl(nbr, nbr) == (u32)lane;
         const bool merge = mutual && lane < nbr, absorbed = mutual && lane > nbr;
         const u32 id_nb = (u32)__shfl((int)id, nbr);
@@ -162,6 +169,13 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
                 const int sA = 24 * t + 2 * rl, sB = sA + 1;
                 const Box bA = (sA >= lo && sA < hi) ? lds_box(s, sA) : box_empty(), bB = (sB >= lo && sB < hi) ? lds_box(s, sB) : box_empty();
                 const int limA = (rl < 12 && sA >= lo) ? hi - sA : 0, limB = (rl < 12 && sB >= lo) ? hi - sB : 0;   // pair (s, s + r) exists iff r < lim
+                // an entry's own candidates (s, s + r): running minimum of the same 64-bit key in a register pair — one v_min_f64 each (a non-negative f32 area as the
+                // high word makes the key a non-negative finite f64, which orders like its bit pattern; hploc.hip, HP_NN_LDS = 3) — and ONE atomic at the end
+                // (the entry's word also collects the keys of the pairs (s - r, s), from this and from other rows): 18 LDS atomics per lane and tile instead of 32.
+                // Only in the 1024-thread instantiation (lists below PLOC_NARROW_MIN chunks: 262 144 0.3744 -> 0.3693 ms); the 512-thread one runs at 96 VGPRs and
+                // would spill the two accumulators (10 M 2.158 -> 2.204 ms)
+                constexpr bool OWN = PLOC_NN_OWN_F64 && PL_BLOCK == 1024;
+                double ownA = __longlong_as_double(0x7FEFFFFFFFFFFFFFll), ownB = ownA;
                 auto cand = [&](const Box& nA, const Box& nB, const int r) {
                     const v2f_t lx = { fminf(nA.lx, bA.lx), fminf(nB.lx, bB.lx) }, ly = { fminf(nA.ly, bA.ly), fminf(nB.ly, bB.ly) }, lz = { fminf(nA.lz, bA.lz), fminf(nB.lz, bB.lz) };
                     const v2f_t hx = { fmaxf(nA.hx, bA.hx), fmaxf(nB.hx, bB.hx) }, hy = { fmaxf(nA.hy, bA.hy), fmaxf(nB.hy, bB.hy) }, hz = { fmaxf(nA.hz, bA.hz), fmaxf(nB.hz, bB.hz) };
@@ -169,17 +183,23 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
                     const unsigned long long kA = (unsigned long long)__float_as_uint(area.x) << 32, kB = (unsigned long long)__float_as_uint(area.y) << 32;
                     if (r < limA) {
                         atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA + r), kA | (u32)sA);
-                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA), kA | (u32)(sA + r));
+                        if constexpr (OWN) ownA = __builtin_fmin(ownA, __longlong_as_double((long long)(kA | (u32)(sA + r))));
+                        else atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA), kA | (u32)(sA + r));
                     }
                     if (r < limB) {
                         atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB + r), kB | (u32)sB);
-                        atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB), kB | (u32)(sB + r));
+                        if constexpr (OWN) ownB = __builtin_fmin(ownB, __longlong_as_double((long long)(kB | (u32)(sB + r))));
+                        else atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB), kB | (u32)(sB + r));
                     }
                 };
                 cand(bB, row_shl<1>(bA), 1);               cand(row_shl<1>(bA), row_shl<1>(bB), 2);
                 cand(row_shl<1>(bB), row_shl<2>(bA), 3);   cand(row_shl<2>(bA), row_shl<2>(bB), 4);
                 cand(row_shl<2>(bB), row_shl<3>(bA), 5);   cand(row_shl<3>(bA), row_shl<3>(bB), 6);
                 cand(row_shl<3>(bB), row_shl<4>(bA), 7);   cand(row_shl<4>(bA), row_shl<4>(bB), 8);
+                if constexpr (OWN) {
+                    if (1 < limA) atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sA), (unsigned long long)__double_as_longlong(ownA));
+                    if (1 < limB) atomicMin(reinterpret_cast<unsigned long long*>(s.nn + sB), (unsigned long long)__double_as_longlong(ownB));
+                }
             }
         }
 }
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         __syncthreads();
         u32 c = C;
         while (c > 1) {
-            if (c <= (u32)WAVE) { if (tid < WAVE) ploc_tail_wave(s, c, nodes, tid); break; }         // (block-uniform; the list in LDS is complete: barrier above / at the loop's end)
+            if (c <= (u32)WAVE) { if (tid < WAVE) ploc_tail_wave<PLOC_NN_OWN_F64 && PL_BLOCK == 1024>(s, c, nodes, tid); break; }         // (block-uniform; the list in LDS is complete: barrier above / at the loop's end)
 #if PLOC_TAIL_PAIRS
             for (int k = tid; k < (int)c; k += PL_BLOCK) s.nn[k] = ~0ull;                             // :131-148, range clipped to [0,c): every pair once, as in the
             __syncthreads();                                                                        // iterations (nearest() reads 16 neighbour boxes per cluster from LDS)
