@@ -127,6 +127,9 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
 #define HP_NN_SCALAR 1     // 1 (default since round 3): nn_search evaluates one candidate per step with scalar f32 operations — fewer live registers (the tile kernel
                            //    no longer spills at 7 waves per SIMD) and each pair's atomics leave as soon as its area exists: tile kernel 0.714 -> 0.67 ms; 0: two per step, packed f32
 #endif
+#ifndef HP_NN_BF
+#define HP_NN_BF 0         // A/B switch: 1 = no branches around the candidates of nn_search (HP_NN_LDS = 3 only)
+#endif
 #ifndef HP_NN_LDS
 #define HP_NN_LDS 3        // neighbour selection.  3 (default since round 4): the pair's key is minimised into the FAR end's word by an LDS atomic (the reference's formulation) and into
                            //    the lane's own running minimum by ONE v_min_f64 on the same 64-bit key (eight LDS atomics per round instead of sixteen; k_hploc_ext 0.200 -> 0.195 ms,
@@ -173,7 +176,18 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
         const float ex = fmaxf(nb.hx, b.hx) - fminf(nb.lx, b.lx), ey = fmaxf(nb.hy, b.hy) - fminf(nb.ly, b.ly), ez = fmaxf(nb.hz, b.hz) - fminf(nb.lz, b.lz);
         const float half_area = ex * ey + ex * ez + ey * ez;                     // Aabb::area (:361-365): 2 * (xy + xz + yz)
         const u32 ab = __float_as_uint(half_area + half_area);                   // (x + x == 2 * x exactly)
+#if HP_NN_BF && HP_NN_LDS == 3
+        // branch-free (tile kernel only: its key words have eight spare ones behind the last wave's): a pair that does not exist sends all ones to the far end's
+        // word (never wins; lanes 56..63 reach into the next wave's first words) and the largest finite key to the own minimum
+        const bool valid = act && (u32)(slot + rr) < cnt;
+        if (PUBLISH) {
+            atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)(valid ? ab : 0xFFFFFFFFu) << 32) | (u32)slot);
+            own = __builtin_fmin(own, __longlong_as_double((long long)(((unsigned long long)(valid ? ab : 0x7FEFFFFFu) << 32) | (u32)(slot + rr))));
+        }
+        if (!PUBLISH && valid) {
+#else
         if (act && (u32)(slot + rr) < cnt) {                                     // both ends are clusters of this task
+#endif
             atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
 #if HP_NN_LDS == 2
             if (ab < abR) { abR = ab; idR = slot + rr; }
@@ -765,7 +779,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     if (tid_x() == 0 && n == 0xFFFFFFFFu) s_pad[bid_x() % (ABL_LDS_PAD / 4)] = 1u;
 #endif
 
-    const int tid = tid_x(), lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int tid = tid_x(), lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: an SGPR — the level loop's task dealing is scalar arithmetic and scalar branches)
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
 #ifdef ABL_TILE_PHASES    // measurement build: where a tile spends its life, as thread 0 sees it (clock ticks summed over the tiles into words 4.. of every sub-queue's padded head;
     __shared__ u64 s_ph[8];                                               // (stamps go straight to LDS: no register lives across the kernel for them)          // tools/tile_phases.py): start, staged, ranges + level sort done, level loop done, hand-over done; barrier waits of the loop
@@ -1023,8 +1037,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     while (lvm[lw]) {
         const int lv = lw * 64 + (int)__builtin_ctzll(lvm[lw]);                        // block-uniform
         lvm[lw] &= lvm[lw] - 1ull;
-        const u32 c = s_cnt[lv];
-        const u32 base = s_off[lv];
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)s_cnt[lv]);             // (block-uniform: the deal below is scalar arithmetic and a scalar loop)
+        const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)s_off[lv]);
 #if HPB_PRIO == 1
         if (c <= 2u) __builtin_amdgcn_s_setprio(3); else if (c <= 4u) __builtin_amdgcn_s_setprio(2); else if (c <= 8u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1370,8 +1384,8 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
     const WaveList wl{ nullptr, nullptr, nullptr, nullptr };
 #endif
     const u32 nwaves = nbid_x() * (256 / WAVE);
-    const u32 wid = bid_x() * (256 / WAVE) + (tid_x() >> 6);
-    const u32 sub = wid % HPQ_SUB;                                       // (nwaves is a multiple of HPQ_SUB)
+    const u32 wid = bid_x() * (256 / WAVE) + (u32)__builtin_amdgcn_readfirstlane((int)(tid_x() >> 6));   // (wave-uniform: the sub-queue's index, base and length live in SGPRs —
+    const u32 sub = wid % HPQ_SUB;                                       //  as vector values two of them were spilled to scratch at 80 VGPRs; nwaves is a multiple of HPQ_SUB)
     const u32 total = q_count[sub * 32u];
 #ifdef ABL_EXT_TRACE
     u64* const trace = const_cast<u64*>(q_rng) + (size_t)q_cap * (HPQ_SUB - 1) + q_cap / 2u;      // the unused second half of the last sub-queue's storage
