@@ -1496,7 +1496,10 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");
-    const u32 xg = 2048u;                               // 8 waves per SIMD (measured flat from 2048 to 8192 workgroups); a multiple of 16:
+#ifndef HPX_GRID
+#define HPX_GRID 2048u
+#endif
+    const u32 xg = HPX_GRID;                            // (measured flat from 2048 to 8192 workgroups; at HPX_OCC = 6, 1536 are resident); a multiple of 16:
                                                         // waves are dealt to the 64 sub-queues round-robin
 #define HPX_LAUNCH(KK, TT) hipLaunchKernelGGL((k_hploc_ext<KK, TT>), dim3(xg), dim3(256), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, (bvh_primref*)d_leaves, \
                        (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, (const u32*)sc.queue_pc, (const u64*)sc.queue_rng, sc.queue_count, q_cap, n)
