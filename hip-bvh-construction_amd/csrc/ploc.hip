@@ -25,6 +25,15 @@ namespace bvh {
 #ifndef PLOC_NN_OWN_F64
 #define PLOC_NN_OWN_F64 1   // 1 (round 4): nn_pairs keeps an entry's own candidates in registers (v_min_f64 on the 64-bit key) and sends one atomic per entry; 0: both ends of every pair by LDS atomics
 #endif
+#ifndef PLOC_LATE
+#define PLOC_LATE 0          // A/B switch (off): 1 = the iterations of a list of at most PLOC_LATE_WG chunks run in ONE launch (k_ploc_late: a barrier between iterations instead of a
+                             //    launch boundary).  Same trees; measured slower — Sponza-like 262 144 0.3735 -> 0.3941 ms, 50 000 0.2366 -> 0.2516, 2 M / 10 M unchanged: an iteration
+                             //    inside the launch is a chain of ~7 coherent round trips (barrier poll, count, span, look-back, drain, arrival) at 1-1.6 us each; the launch boundary
+                             //    it replaces (5.4 us for a launch that finds nothing to do) is cheaper (LEADS.md row 75)
+#endif
+#ifndef PLOC_LATE_WG
+#define PLOC_LATE_WG 16
+#endif
 #ifndef PLOC_TAIL_PAIRS
 #define PLOC_TAIL_PAIRS 1
 #endif
@@ -70,6 +79,22 @@ __device__ __forceinline__ void entry_load(const float4* __restrict__ list, size
 __device__ __forceinline__ void entry_store(float4* __restrict__ list, size_t g, u32 id, const Box& b) {
     list[2 * g] = make_float4(__uint_as_float(id), b.lx, b.ly, b.lz);
     list[2 * g + 1] = make_float4(b.hx, b.hy, b.hz, 0.0f);
+}
+
+// the same entry written / read by different workgroups of ONE launch (k_ploc_late): 8-byte agent-scope accesses (sc1: the XCDs' L2s are not coherent with each other);
+// the writer drains its stores before it arrives at the launch's barrier
+template <bool AGENT>
+__device__ __forceinline__ void entry_load_t(const float4* __restrict__ list, size_t g, u32& id, Box& b) {
+    if (!AGENT) { entry_load(list, g, id, b); return; }
+    const u64* q = reinterpret_cast<const u64*>(list + 2 * g);
+    const u64 w0 = ld_agent(q), w1 = ld_agent(q + 1), w2 = ld_agent(q + 2), w3 = ld_agent(q + 3);
+    id = (u32)w0; b = { hi_f(w0), lo_f(w1), hi_f(w1), lo_f(w2), hi_f(w2), lo_f(w3) };
+}
+template <bool AGENT>
+__device__ __forceinline__ void entry_store_t(float4* __restrict__ list, size_t g, u32 id, const Box& b) {
+    if (!AGENT) { entry_store(list, g, id, b); return; }
+    u64* q = reinterpret_cast<u64*>(list + 2 * g);
+    st_agent(q, (u64)id | ((u64)__float_as_uint(b.lx) << 32)); st_agent(q + 1, pack2(b.ly, b.lz)); st_agent(q + 2, pack2(b.hx, b.hy)); st_agent(q + 3, pack2(b.hz, 0.0f));
 }
 
 // nearest neighbour of span entry k among valid entries [lo, hi) within +-8, key {area bits, position}
@@ -210,15 +235,19 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
 #ifndef PLOC_OCC
 #define PLOC_OCC 5
 #endif
-template <int PL_BLOCK, bool FIRST>
-__global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
-                                                        bvh2_node* __restrict__ nodes,
-                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
-                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
+// One iteration as workgroup `wg` of `G`.  Returns true when the build is over (one cluster left, or this workgroup has nothing more to do in it).
+// LATE (k_ploc_late: several iterations in one launch, a barrier between them): chunks are dealt statically (wg, wg + G, ...: all G workgroups are resident), list
+// entries and counts go through agent-scope accesses (they cross workgroups INSIDE the launch), and a final count is written to every counts[1 .. n_fwd] (the
+// per-iteration launches pass it on one launch at a time: the host reads the batch's last word).
+template <int PL_BLOCK, bool FIRST, bool LATE>
+__device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restrict__ list_in, float4* __restrict__ list_out, bvh2_node* __restrict__ nodes,
+                                               u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
+                                               const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
+                                               const u32 wg, const u32 G, const u32 n_fwd) {
     constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
-    __shared__ PlocLds s;
-    const u32 C = counts[0];
-    if (C <= 1) { if (bid_x() == 0 && tid_x() == 0) counts[1] = C; return; }
+    const u32 C = LATE ? ld_agent(counts) : counts[0];
+    auto set_count = [&](u32 v) { if (LATE) { for (u32 j = 1; j <= n_fwd; ++j) st_agent(counts + j, v); } else counts[1] = v; };
+    if (C <= 1) { if (wg == 0 && tid_x() == 0) set_count(C); return true; }
     const int tid = tid_x();
     // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
     auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
@@ -230,13 +259,13 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
                 reinterpret_cast<u32*>(f)[0] = prim;
                 f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
             }
-        } else entry_load(list_in, g, id, b);
+        } else entry_load_t<LATE>(list_in, g, id, b);
     };
 
     auto nn_pairs = [&](const int lo, const int hi) { nn_pairs_fn<PL_BLOCK>(s, tid, lo, hi); };
     if (C < (u32)PLOC_CHUNK) {
         // ---- tail: the whole list in one workgroup until a single cluster remains (SinglePassPloc :98-209)
-        if (bid_x() != 0) return;
+        if (wg != 0) return true;
         for (int k = tid; k < (int)C; k += PL_BLOCK) { u32 id; Box b; fetch((size_t)k, true, id, b); lds_set(s, k, id, b); }
         __syncthreads();
         u32 c = C;
@@ -284,8 +313,8 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
             __syncthreads();
             c = tot & 0xFFFFu;
         }
-        if (tid == 0) { counts[1] = 1; atomicAdd(iters_done, 1u); }
-        return;
+        if (tid == 0) { set_count(1u); atomicAdd(iters_done, 1u); }
+        return true;
     }
 
     // ---- one global iteration (Ploc :211-362), persistent over chunk tickets.  A chunk's compacted output needs the totals of all
@@ -326,7 +355,11 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
             }
             if (tid == 0) {
                 s.bcast[1] = (u32)(excl >> 31); s.bcast[2] = (u32)(excl & 0x7FFFFFFFull);
-                if (chunk == chunks - 1) { counts[1] = C - ((u32)(excl >> 31) + (tot >> 16)); atomicAdd(iters_done, 1u); }   // src/PLOC++Bvh.cpp:150
+                if (chunk == chunks - 1) {                                                                                   // src/PLOC++Bvh.cpp:150
+                    const u32 left = C - ((u32)(excl >> 31) + (tot >> 16));
+                    if (LATE) st_agent(counts + 1, left); else counts[1] = left;
+                    atomicAdd(iters_done, 1u);
+                }
             }
         }
         __syncthreads();
@@ -339,16 +372,18 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
                     id = C - 2 - (m_ex + (ex >> 16));                                                // :311
                     node_store_plain(nodes + id, cid[q], pid[q], cb[q]);
                 }
-                if (PLOC_ABL != 3) entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);                   // :355-361
+                if (PLOC_ABL != 3) entry_store_t<LATE>(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);           // :355-361
             }
             ex += ((u32)mrg[q] << 16) + (u32)keep[q];
         }
     };
-    while (true) {
+    for (u32 trip = 0; ; ++trip) {
         __syncthreads();
-        if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
-        __syncthreads();
-        const u32 chunk = s.bcast[0];
+        if (!LATE) {
+            if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
+            __syncthreads();
+        }
+        const u32 chunk = LATE ? wg + trip * G : s.bcast[0];
         if (chunk >= chunks) break;
         const long long o = (long long)chunk * PLOC_CHUNK;
         // span entry k <-> list position o - HALO + k   (:232-249)
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
                 const long long gpos = o - PL_HALO + k;
                 in_[q] = k < PL_SPAN && gpos >= 0 && gpos < (long long)C;
                 const size_t gc = in_[q] ? (size_t)gpos : (size_t)o;                 // (o < C: the chunk exists)
-                if (FIRST) prim_[q] = svals[gc]; else entry_load(list_in, gc, id_[q], b_[q]);
+                if (FIRST) prim_[q] = svals[gc]; else entry_load_t<LATE>(list_in, gc, id_[q], b_[q]);
             }
             if (FIRST) {
 #pragma unroll
@@ -426,12 +461,52 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
         // `chunks` different workgroups, so nobody needs to ask again just to learn that the list is used up — the finish below starts a round trip earlier
         // Measured on the MI355X (whole build, same box): Sponza-like 262 144 0.4107 -> 0.4065 ms, 524 288 0.5216 -> 0.5180, uniform 1 M 0.5630 -> 0.5605; but 2 M
         // 0.783 -> 0.790 and 10 M 2.206 -> 2.245 (there the second ticket's round trip is what gives the predecessors time to publish before the walk): small inputs only
-        if (nbid_x() >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;              // (grid-uniform)
+        if (!LATE && G >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;            // (grid-uniform)
 #endif
     }
 #if PLOC_DEFER
     if (p_have) { __syncthreads(); finish(p_chunk, p_tot, p_ex, p_cid, p_pid, p_cb, p_mrg, p_keep); }
 #endif
+    return false;
+}
+
+template <int PL_BLOCK, bool FIRST>
+__global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
+                                                        bvh2_node* __restrict__ nodes,
+                                                        u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
+                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
+    __shared__ PlocLds s;
+    (void)ploc_iter_body<PL_BLOCK, FIRST, false>(s, list_in, list_out, nodes, status, counts, tickets, iters_done, ni, boxes, svals, leaves, bid_x(), nbid_x(), 1u);
+}
+
+// The late iterations in ONE launch (round 4).  Traced at Sponza-like 262 144 (tools/prof_ploc.sh): an iteration launch that finds nothing to do takes 5.4 us from
+// start to end, the iterations of the last <= 16 chunks 7.2-7.7 us each — two thirds of a late iteration is the launch boundary.  Here PLOC_LATE_WG workgroups run
+// iterations k_begin .. k_end - 1 back to back: static chunks (workgroup w takes w, w + G, ...), the usual look-back inside an iteration, and between two iterations
+// a barrier on the iteration's (otherwise unused) ticket word: every wave drains its write-through list stores, one thread arrives and polls until all G have.  The
+// list entries and the counts cross workgroups inside the launch: agent-scope accesses (ploc_iter_body<LATE>).  G is small (16 x 1024 threads of a device that holds
+// 512 such workgroups), so the launch's workgroups are resident together whenever the stream has the device's attention; were some of them delayed by other streams'
+// kernels, the others wait at the barrier / in the look-back until those kernels end — nothing here waits for a workgroup that can never start.
+// Same result as the per-iteration launches: the chunking does not enter the result (the look-back's prefix sums are those of the list order), and it never did —
+// the ticket order of k_ploc_iter is not deterministic either.
+template <int PL_BLOCK>
+__global__ __launch_bounds__(PL_BLOCK, 4) void k_ploc_late(float4* list0, float4* list1, bvh2_node* __restrict__ nodes, u64* status_base, u32 chunks_n,
+                                                           u32* counts_base, u32* tickets_base, u32* iters_done, u32 ni, u32 k_begin, u32 k_end, u32 parity) {
+    __shared__ PlocLds s;
+    const u32 G = nbid_x(), wg = bid_x();
+    for (u32 k = k_begin; k < k_end; ++k) {
+        const bool even = ((k + parity) & 1u) == 0u;
+        const float4* in = even ? list0 : list1; float4* out = even ? list1 : list0;
+        if (ploc_iter_body<PL_BLOCK, false, true>(s, in, out, nodes, status_base + (size_t)k * chunks_n, counts_base + k, tickets_base + k, iters_done, ni,
+                                                  nullptr, nullptr, nullptr, wg, G, k_end - k)) return;
+        if (k + 1 == k_end) return;
+        drain_stores();                                  // this wave's list entries (and the next count) are in memory ...
+        __syncthreads();                                 // ... and so are the other waves' ...
+        if (tid_x() == 0) {                              // ... before the workgroup arrives
+            __hip_atomic_fetch_add(tickets_base + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (ld_agent(tickets_base + k) < G) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
 }
 
 // =====================================================================================================================
@@ -622,6 +697,13 @@ void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_node
         u32 grid = (u32)(2.0 * guess) + 8u; if (grid > (wide ? 512u : 1024u)) grid = wide ? 512u : 1024u; if (grid > chunks) grid = chunks;
         const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);
         const bool f0 = fresh && k == first;
+#if PLOC_LATE
+        if (!f0 && guess <= (double)PLOC_LATE_WG) {      // the rest of the batch in one launch (the guess is generous: the list has at most that many chunks)
+            hipLaunchKernelGGL((k_ploc_late<1024>), dim3(PLOC_LATE_WG < chunks ? PLOC_LATE_WG : chunks), dim3(1024), 0, s, (float4*)sc.list0, (float4*)sc.list1, (bvh2_node*)d_nodes,
+                               sc.status, chunks, counts, tickets, done, n - 1, (u32)k, (u32)(first + count), (u32)parity);
+            break;
+        }
+#endif
 #define PLOC_LAUNCH(BLK, FIRST) hipLaunchKernelGGL((k_ploc_iter<BLK, FIRST>), dim3(grid), dim3(BLK), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, \
                                                    counts + k, tickets + k, done, n - 1, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves)
         if (wide) { if (f0) PLOC_LAUNCH(1024, true); else PLOC_LAUNCH(1024, false); }

@@ -1,5 +1,5 @@
 """GPU: a non-default build of the kernels (build/variants/libbvh_alt.so from __graft_entry__.build(): both ends of the neighbour selection by LDS atomics, whole-wave
-lone rounds, PLOC++'s round-1 tail search) produces the same trees as the oracle and as the production library — the A/B switches kept in the sources are not dead code."""
+lone rounds, PLOC++'s round-1 tail search and its late iterations in one launch) produces the same trees as the oracle and as the production library — the A/B switches kept in the sources are not dead code."""
 import json
 import os
 import subprocess

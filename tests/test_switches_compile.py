@@ -19,7 +19,7 @@ SETS = [
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DHPB_LEAN=0", "-DHPB_OCC=7", "-DHPB_DEPS=1", "-DHP_NN_BF=1", "-DHPB_WIDE=1", "-DHPX_LDS_LIST=1", "-DHPB_PRIO=1", "-DHPB_ROT=1"]),
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DHP_NN_LDS=2", "-DHP_NN_SCALAR=0", "-DHPB_PREPROBE=0", "-DHPB_PAIR_SORT=0", "-DHPB_STAGE_SERIAL_GATHER=0", "-DBVH_ABLATION"]),
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DHP_NN_LDS=0", "-DHPB_LEAN=0", "-DHPB_OCC=7"]),
-    ("ploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DPLOC_NN_OWN_F64=0", "-DPLOC_TAIL_PAIRS=0", "-DPLOC_ONE_SHOT=0", "-DPLOC_DEFER=0"]),
+    ("ploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DPLOC_NN_OWN_F64=0", "-DPLOC_TAIL_PAIRS=0", "-DPLOC_ONE_SHOT=0", "-DPLOC_DEFER=0", "-DPLOC_LATE=1"]),
     ("sort.hip", [], ["-DSORT_NT=3", "-DSORT_PRIO=1", "-DSORT_EARLY_PUBLISH=1", "-DSORT_EXCHANGE_FIRST=1", "-DBVH_ABLATION"]),
     ("lbvh.hip", EMIT, ["-DLBVH_EXT_MAX_SHIFT=6", "-DBVH_ABLATION"]),
 ]

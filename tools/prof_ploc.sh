@@ -9,10 +9,13 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 it = [(s, e) for n, s, e in rows if "k_ploc_iter" in n]
-# last build = last group of launches; split builds by k_ploc_init
-setups = [s for n, s, e in rows if "k_ploc_init" in n]
-last = setups[-1]
-it = [(s, e) for s, e in it if s > last]
+# last build = last group of launches; split builds by stage E's launch
+setups = [s for n, s, e in rows if "k_extents" in n]       # (k_ploc_init is part of stage E's kernel since round 3)
+allit = it
+for k in range(len(setups) - 1, -1, -1):                   # the last build that launched iterations (later stage-E launches belong to other builders' loops)
+    hi = setups[k + 1] if k + 1 < len(setups) else float("inf")
+    it = [(s, e) for s, e in allit if setups[k] < s < hi]
+    if it: break
 print("launches in last build:", len(it))
 t0 = it[0][0]
 for i, (s, e) in enumerate(it):
