@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round
 rm -rf $O; mkdir -p $O
 python $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-secondary > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --cpu-sample 0 --no-secondary > $O/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events --no-secondary > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events --no-secondary > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $O/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-kernel-events --no-secondary > $O/pmc_sq.log 2>&1

@@ -17,7 +17,7 @@ sec = ["## bench line (`profiles/%s_bench.json`)\n\n" % rnd,
        "from this run and carry the hash `%s` of the sources): %s\n\n" % (rf["profiles_match_kernel_sources"]["kernel_source_hash"], json.dumps(rf)),
        "`pipeline_roofline`: %s\n\n" % json.dumps(b["pipeline_roofline"]), "`cpu_baseline`: %s\n\n" % json.dumps(b["cpu_baseline"]),
        "`secondary`:\n" + "".join("* %s\n" % json.dumps(x) for x in b["secondary"]) + "\n",
-       "## rocprofv3 --kernel-trace --stats (24 builds: 3 warm-up + 20 timed + 1 stage-timed)\n\n" + open(os.path.join(O, "stats.md")).read().strip() + "\n\n",
+       "## rocprofv3 --kernel-trace --stats (the bench command itself without its CPU leg and secondary loops: 206 builds = 5 warm-up + 200 timed + 1 stage-timed)\n\n" + open(os.path.join(O, "stats.md")).read().strip() + "\n\n",
        "## HBM traffic per build (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KB units; MI355X_MICROARCH.md's gfx950 correction)\n\n" + open(os.path.join(O, "traffic.md")).read().strip() + "\n\n",
        "## issue (SQ counters, priced: profiles/r04_direct_counters.md for the direct ones)\n\n" + open(os.path.join(O, "issue.md")).read().strip() + "\n\n"]
 open(path, "w").write(s[:i0] + "".join(sec) + s[i1:])

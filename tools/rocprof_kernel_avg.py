@@ -14,7 +14,7 @@ from _srchash import kernel_source_hash
 def main():
     db = sqlite3.connect(sys.argv[1]); n = int(sys.argv[2])
     rows = db.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels group by name").fetchall()
-    out = {"_kernel_source_hash": kernel_source_hash(), "_source": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-secondary"}
+    out = {"_kernel_source_hash": kernel_source_hash(), "_source": "rocprofv3 --kernel-trace --stats -- python bench.py --cpu-sample 0 --no-secondary (the default 200 timed builds)"}
     for name, cnt, avg, mn, mx in rows:
         k = name.split("(")[0].replace("void ", "").replace("bvh::", "").split("<")[0]
         if k.startswith("k_"):
