@@ -76,3 +76,40 @@ def test_cpp_host_mirror_compiles():
     src = os.path.join(ROOT, "examples", "build_example.cpp")
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+# ---- the LINKED gfx950 code objects of the emit kernels (round 4: what `hipcc -S` shows is not what ships) ------------------------------------------------
+def _code_object(obj, tmp):
+    """unbundle the gfx950 code object of a `hipcc -c` object file; returns (disassembly, notes) or None when the LLVM tools are missing"""
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(tools, "clang-offload-bundler")) and os.path.exists(obj)):
+        return None
+    fat, co = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.co")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    subprocess.run([os.path.join(tools, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"], check=True)
+    dis = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    return dis, notes
+
+
+@pytest.mark.parametrize("src", ["hploc", "ploc", "lbvh", "collapse"])
+def test_emit_kernels_have_no_calls_and_the_hot_ones_no_scratch(pkg, src, tmp_path):
+    """-mno-amdgpu-ieee keeps the device library's __ockl_get_local_id & co. from being inlined (different IEEE-mode attribute): the kernels must use the builtin ids
+    (common.hpp tid_x / bid_x / nbid_x).  And nbid_x() reads the FIRST hidden kernel argument: that must be hidden_block_count_x (code object v5 layout)."""
+    got = _code_object(os.path.join(ROOT, "hip-bvh-construction_amd", "csrc", src + ".o"), str(tmp_path))
+    if got is None:
+        pytest.skip("LLVM tools or the object file are missing")
+    dis, notes = got
+    assert "s_swappc" not in dis, f"{src}.o: a device function call survived linking"
+    kernels = re.findall(r"\.args:(.*?)\.name:\s+(\S+)", notes, flags=re.S)
+    assert kernels
+    for args, name in kernels:
+        kinds = re.findall(r"\.value_kind:\s+(\S+)", args)
+        hidden = [k for k in kinds if k.startswith("hidden_")]
+        if hidden:
+            assert hidden[0] == "hidden_block_count_x", (name, hidden[:3])
+    if src == "hploc":
+        for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", notes, flags=re.S):
+            if "k_hploc_block" in m.group(1) or "k_hploc_ext" in m.group(1):
+                assert int(m.group(2)) == 0, (m.group(1), "spills to scratch")
