@@ -11,7 +11,7 @@ from conftest import ROOT
 
 CSRC = os.path.join(ROOT, "hip-bvh-construction_amd", "csrc")
 BASE = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-        "--cuda-device-only", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"]
+        "--cuda-device-only", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"]
 EMIT = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 
 SETS = [

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/build/variants; OBJ=$ROOT/build/variants/obj_$NAME
 mkdir -p $OBJ
 cd $ROOT/hip-bvh-construction_amd/csrc
-FLAGS="-DBVH_ABLATION -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I. -Wno-unused-value -Wno-unused-result -Wno-pass-failed"
+FLAGS="-DBVH_ABLATION -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off ${KPRELOAD--mllvm -amdgpu-kernarg-preload-count=16} -I$ROOT/include -I. -Wno-unused-value -Wno-unused-result -Wno-pass-failed"
 for f in api stage_em sort misc trace batched; do [ -f $OBJ/$f.o ] && [ $OBJ/$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o $OBJ/$f.o & done
 for f in lbvh collapse; do /opt/rocm/bin/hipcc $FLAGS -fno-honor-nans -mno-amdgpu-ieee $EXTRA -c $f.hip -o $OBJ/$f.o & done
 for f in hploc ploc; do /opt/rocm/bin/hipcc $FLAGS -fno-honor-nans -mno-amdgpu-ieee ${NOSLP--fno-slp-vectorize} $EXTRA -c $f.hip -o $OBJ/$f.o & done     # (as the Makefile; NOSLP="" builds them with the SLP vectoriser)
