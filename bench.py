@@ -73,7 +73,7 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     d = os.path.join(ROOT, "hip-bvh-construction_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":       # (the compile flags are part of what was measured: round 4)
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
