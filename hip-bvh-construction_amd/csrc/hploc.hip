@@ -1509,4 +1509,8 @@ void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys,
 #undef HPX_LAUNCH
 }
 
+// (kernels.hpp: touching one kernel of this translation unit makes the runtime load its code object — bvh_ctx_create does that for the build path's modules, so
+// that a context's FIRST build does not pay for it: 0.3-0.7 ms per module on the MI355X, tools/cold_probe.py)
+void warm_hploc() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_hploc<u32>)); }
+
 } // namespace bvh

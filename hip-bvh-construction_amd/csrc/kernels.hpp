@@ -171,4 +171,7 @@ void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, u
 void launch_bvh4_cost(hipStream_t s, const void* d_wide, uint32_t n_wide, const void* d_prims, const void* d_prim_boxes, uint32_t n, double* d_out /*[1], zeroed inside*/);
 void launch_checksum(hipStream_t s, const void* d_nodes, uint32_t n_nodes, const void* d_leaves /*may be null*/, uint32_t n_leaves, uint32_t root, uint64_t* d_out /*[1], zeroed inside*/);
 
+// one kernel of each translation unit of the build path is touched (hipFuncGetAttributes): the runtime loads that unit's code object now instead of at its first launch
+void warm_stage_em(); void warm_sort(); void warm_lbvh(); void warm_hploc(); void warm_ploc(); void warm_misc(); void warm_collapse();
+
 } // namespace bvh

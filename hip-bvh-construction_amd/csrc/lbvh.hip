@@ -359,4 +359,8 @@ void launch_lbvh_two(hipStream_t s, const void* d_boxes, const void* d_skeys, in
     { KernelScope ks(s, "k_refit"); hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(LBVH_BLOCK), 0, s, (bvh2_node*)d_nodes, (const u32*)d_parent, d_flags, n); }
 }
 
+// (kernels.hpp: touching one kernel of this translation unit makes the runtime load its code object — bvh_ctx_create does that for the build path's modules, so
+// that a context's FIRST build does not pay for it: 0.3-0.7 ms per module on the MI355X, tools/cold_probe.py)
+void warm_lbvh() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_refit)); }
+
 } // namespace bvh

@@ -174,4 +174,8 @@ void launch_sah_cost(hipStream_t s, const void* d_nodes, const void* d_leaves, u
     hipLaunchKernelGGL(k_sah, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, s, (const bvh2_node*)d_nodes, (const bvh_primref*)d_leaves, root, n, layout, d_out);
 }
 
+// (kernels.hpp: touching one kernel of this translation unit makes the runtime load its code object — bvh_ctx_create does that for the build path's modules, so
+// that a context's FIRST build does not pay for it: 0.3-0.7 ms per module on the MI355X, tools/cold_probe.py)
+void warm_misc() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_readback)); }
+
 } // namespace bvh

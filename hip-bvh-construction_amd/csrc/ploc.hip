@@ -712,4 +712,8 @@ void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_node
     }
 }
 
+// (kernels.hpp: touching one kernel of this translation unit makes the runtime load its code object — bvh_ctx_create does that for the build path's modules, so
+// that a context's FIRST build does not pay for it: 0.3-0.7 ms per module on the MI355X, tools/cold_probe.py)
+void warm_ploc() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_init)); }
+
 } // namespace bvh

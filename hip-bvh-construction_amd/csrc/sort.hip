@@ -482,4 +482,8 @@ void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in,
     sort_pairs_t<u64>(s, sc, keys_in, vals_in, n, keys_out, vals_out, start_bit, end_bit, hist_ready);
 }
 
+// (kernels.hpp: touching one kernel of this translation unit makes the runtime load its code object — bvh_ctx_create does that for the build path's modules, so
+// that a context's FIRST build does not pay for it: 0.3-0.7 ms per module on the MI355X, tools/cold_probe.py)
+void warm_sort() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_iota)); }
+
 } // namespace bvh

@@ -458,4 +458,8 @@ void launch_morton64(hipStream_t s, const void* d_boxes, u32 n, const void* d_sc
                        d_hist, d_hist ? passes : 0, d_reset_next);
 }
 
+// (kernels.hpp: touching one kernel of this translation unit makes the runtime load its code object — bvh_ctx_create does that for the build path's modules, so
+// that a context's FIRST build does not pay for it: 0.3-0.7 ms per module on the MI355X, tools/cold_probe.py)
+void warm_stage_em() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_reset_scene)); }
+
 } // namespace bvh

@@ -30,7 +30,8 @@ extern "C" {
 
 typedef struct bvh_ctx bvh_ctx;
 
-/* Replaces Context::Context() (src/Context.cpp:7-15: device 0 hard coded) — here any device, own stream. */
+/* Replaces Context::Context() (src/Context.cpp:7-15: device 0 hard coded) — here any device, own stream.  The first context of a process on a device also
+ * loads the build path's code objects (~2.6 ms, once), so that no build pays for it: the reference compiles its kernels at this point (hiprtc, seconds). */
 int  bvh_ctx_create(int device, bvh_ctx** out);
 /* Same, but work is enqueued on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
 int  bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out);
