@@ -207,12 +207,17 @@ def main() -> None:
     import ctypes as C
 
     gather_events = []
+    step_no = [0]
 
     def step():
         builder.build(ctx, d_tris, on_device=True, n=n)
         if gather:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)); gather_events.append(ev)
-            ev[0].record(side)
+            # the exchange is bracketed by HIP events on every 8th step only (like the kernels': an event between two launches costs a few microseconds of launch gap,
+            # and these two sat in EVERY step of the N > 1 lines — the N = 1 line has no exchange to bracket)
+            timed = step_no[0] % 8 == 0; step_no[0] += 1
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
+            if timed:
+                gather_events.append(ev); ev[0].record(side)
             # root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
             src = builder.result.d_nodes + 32 * builder.result.root + 8
             rc = lib.bvh_dev_copy(ctx.handle, root_box.data_ptr(), src, 24)
@@ -222,7 +227,8 @@ def main() -> None:
             else:
                 host = root_box.cpu(); out = [torch.zeros(6) for _ in range(world)]
                 dist.all_gather(out, host)
-            ev[1].record(side)
+            if timed:
+                ev[1].record(side)
 
     def barrier():
         if gather:
@@ -253,7 +259,7 @@ def main() -> None:
         elapsed = float(tmax.item())
     ktimes = {} if args.no_kernel_events else ctx.kernel_times()
     # all-gather of the root boxes: mean / max over the timed steps on this rank, device time incl. the 24-byte staging copy
-    gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_events[-args.steps:]] if gather_events else []
+    gather_us = [a.elapsed_time(b) * 1e3 for a, b in gather_events[-max(1, args.steps // 8):]] if gather_events else []      # (the sampled steps of the timed region)
     if gather and backend == "nccl":      # every rank holds every root box, and this rank's slot is its own tree's root
         torch.cuda.synchronize()
         assert torch.equal(gathered[6 * rank: 6 * rank + 6], root_box), "all-gather of root AABBs is inconsistent"
