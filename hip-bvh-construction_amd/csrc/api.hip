@@ -548,6 +548,9 @@ int bvh_emit_hploc(bvh_ctx* c, const void* d_prim_aabbs, const uint32_t* d_sorte
 #ifndef LEAF_FROM_TRIS
 #define LEAF_FROM_TRIS 0
 #endif
+#ifndef SORT_GATE_TOP
+#define SORT_GATE_TOP 1      // 0: the build sorts all 32 key bits at every size (no narrow top pass, no gate)
+#endif
 static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint32_t n, bvh_result* out, bvh_timings* tm) {
     const int key_bits = in->morton_bits == 60 ? 64 : 32;
     hipStream_t s = c->stream;
@@ -563,7 +566,12 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     // the build's own sort runs on bits [0, 30) / [0, 60): four (eight) passes either way, but the last one has a 6-bit (4-bit) digit — 64 digit threads,
     // 6 ballots per key and 64 status words per tile in the look-back instead of 256.  The fused digit histograms of the Morton kernel
     // — (code >> 24) & 255 for the last pass — hold exactly those digits' counts.  (bvh_sort_pairs keeps full generality for caller-supplied keys.)
-    const int end_bit = key_bits == 64 ? 60 : 30;
+    // Round 5: the reference's wrap-around code arithmetic leaves bits 30 / 31 (60..63) set on degenerate scenes (planar, axis ratio >= 2^32).  The u64 sort
+    // therefore runs on all 64 bits (eight passes either way); the u32 sort keeps its 6-bit top pass but gates it on a device word the Morton kernel raises when
+    // such a code exists — the full-width instantiation enqueued behind it then does the pass (SORT_WIDE_FLAG_WORD, kernels.hpp).
+    // Same-box A/B of the gate (gpurun_out/r5_gate_ab.log): + 3 us per build (the second launch) against the 4.5 us the narrow pass saves at 10 M — and nothing to save
+    // below the wide sort tiles' threshold (262 144: 0.1141 -> 0.1165 ms), where the build therefore simply sorts all 32 bits like the reference.
+    const int end_bit = key_bits == 64 ? 64 : (n >= SORT_WIDE_MIN_N && SORT_GATE_TOP != 0) ? 30 : 32;
     const int passes = sort_passes(0, end_bit);
     r = stage_extents_valid(in); if (r) return r;
     // what a build needs cleared (digit histograms, look-back status rows and tile tickets of `passes` sort passes, the emitters' queue heads) is cleared by
@@ -590,7 +598,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
     // S: radix sort (token SortingTime)
     if (key_bits == 64) sort_pairs64(s, c->sort, reinterpret_cast<const u64*>(c->keys), nullptr, n, reinterpret_cast<u64*>(c->skeys), c->svals, 0, end_bit, true);
-    else sort_pairs(s, c->sort, c->keys, nullptr, n, c->skeys, c->svals, 0, end_bit, true);
+    else sort_pairs(s, c->sort, c->keys, nullptr, n, c->skeys, c->svals, 0, end_bit, true, end_bit == 30);
     if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
     // B: hierarchy emit (token BvhBuildTime; SetupClusters is booked here, not under Morton as the reference does)
     out->d_leaves = nullptr; out->layout = 0; out->root = 0;

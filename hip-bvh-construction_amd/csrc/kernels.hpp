@@ -67,6 +67,11 @@ static_assert(SORT_COUNTER_CLEAR >= SORT_MAX_PASSES, "the build path's first ker
 // into ONE copy spent 23 us queueing on every bin (k_morton 88 us at 10 M, of which the stream is 45); with 16 copies it is 1.5 us.
 constexpr int SORT_HIST_COPIES = 16;
 constexpr int SORT_HIST_STRIDE = SORT_MAX_PASSES * (1 << SORT_BITS);
+// The build's u32 sort runs on key bits [0, 30) (8/8/8/6).  The extended Morton code is the reference's unsigned wrap-around arithmetic
+// (src/CommonBlocksKernel.h:252-356) and does NOT stay below 2^30 on every scene (a planar scene with an axis ratio >= 2^32: ADVICE r04) — the reference sorts
+// all 32 bits, so such keys must sort by them.  k_morton raises this word (row 4 of histogram copy 0: unused by a four-pass sort, cleared with the histograms)
+// when a code has bit 30 or 31 set; the narrow last pass then returns at once and the 8-bit instantiation enqueued behind it (a no-op otherwise) does the pass.
+constexpr int SORT_WIDE_FLAG_WORD = 4 * (1 << SORT_BITS);
 struct SortScratch {
     void*     pairs0;        // interleaved {key,value} records of the intermediate passes, ping (8 B x n for u32 keys, 16 B x n for u64)
     void*     pairs1;        // pong
@@ -83,8 +88,9 @@ size_t sort_status_bytes(uint32_t n);
 void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes, float* d_scene_reset = nullptr,
                   uint32_t* d_extra = nullptr, uint32_t extra_words = 0);
 // hist_ready: sc.hist already holds the per-pass digit counts (fused into the Morton kernel); else a histogram kernel runs.
+// gated_narrow_top (the build's u32 path only; needs hist_ready and the flag word maintained by k_morton): see SORT_WIDE_FLAG_WORD
 void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
-                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready);
+                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready, bool gated_narrow_top = false);
 void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n,
                   uint64_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready);
 

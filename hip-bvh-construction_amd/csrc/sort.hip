@@ -108,7 +108,9 @@ template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };  
 #endif
 // BITS: digit width of this instantiation's pass (6..8; a pass whose digit is narrower than BITS passes a smaller digit_mask).  Status rows keep their
 // SORT_RADIX-word stride; a pass only touches the first 2^BITS words of a row.
-template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK, int BITS = SORT_BITS>
+// GATE (SORT_WIDE_FLAG_WORD, kernels.hpp): 1 = the build's narrow top pass, which leaves at once when the Morton kernel saw a code beyond the bit range this
+// pass sorts; 2 = the full-width pass enqueued behind it, which leaves at once when it did not.  ghist + SORT_RADIX is that word for the fourth pass.
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK, int BITS = SORT_BITS, int GATE = 0>
 __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
                                                          int shift, u32 digit_mask, const u32* __restrict__ ghist,
@@ -138,6 +140,9 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #else
 #define SORT_STAMP() do { } while (0)
 #endif
+    if (GATE == 2) { if (ghist[SORT_RADIX] == 0u) return; }      // (uniform; before anything is loaded or written)
+    u32 gate_word = 0u;
+    if (GATE == 1) gate_word = ghist[SORT_RADIX];                 // a scalar load that travels with the tile's key loads; tested behind them
     SORT_STAMP();                                    // 0: start
 #if SORT_PRIO
     __builtin_amdgcn_s_setprio(3);                   // A/B switch (off): a tile runs at high priority until its digit totals are published (its successors wait for them)
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
             val[i] = IOTA ? (base + local) : (ok ? SORT_LD(vals_in + base + local) : 0u);
         }
     }
+    if (GATE == 1) { if (gate_word != 0u) return; }               // (uniform; nothing has been written yet)
 #ifdef BVH_ABLATION
     if (dbg & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -417,7 +423,7 @@ void sort_prepare(hipStream_t s, const SortScratch& sc, uint32_t n, int passes, 
 
 template <typename K>
 static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in, const uint32_t* vals_in, uint32_t n,
-                         K* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
+                         K* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready, bool gated_narrow_top = false) {
     const int passes = sort_passes(start_bit, end_bit);
     if (passes <= 0) {   // nothing to sort on: identity permutation
         (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, s);
@@ -457,13 +463,24 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         KernelScope ks(s, "k_onesweep");
         const dim3 g(tiles), bn(SORT_NARROW_NT), bw(SortWide<K>::NT);
         const int pdbg = dbg | (((dbg & 128) && last) ? 1 : 0);
-#define SWEEP_B(IOTA, INA, OUTA, BB) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT, BB>), g, bw, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, pdbg); \
-                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT, BB>), g, bn, 0, s, kin, vin, kout, vout, n, sh, mask, h, st, tc, pdbg); } while (0)
+#define SWEEP_G(IOTA, INA, OUTA, BB, GG, MASK) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT, BB, GG>), g, bw, 0, s, kin, vin, kout, vout, n, sh, MASK, h, st, tc, pdbg); \
+                                  else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT, BB, GG>), g, bn, 0, s, kin, vin, kout, vout, n, sh, MASK, h, st, tc, pdbg); } while (0)
+#define SWEEP_B(IOTA, INA, OUTA, BB) SWEEP_G(IOTA, INA, OUTA, BB, 0, mask)
 #define SWEEP(IOTA, INA, OUTA) SWEEP_B(IOTA, INA, OUTA, SORT_BITS)
-        if (first && last)      { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
+        bool launched = false;
+        if constexpr (sizeof(K) == 4) {
+            if (last && !first && gated_narrow_top && w == 6 && p == 3 && start_bit == 0 && hist_ready) {
+                SWEEP_G(false, true, false, 6, 1, mask);                  // the build's [24, 30) pass ...
+                SWEEP_G(false, true, false, SORT_BITS, 2, 255u);         // ... or, when a code has bit 30 / 31 set, the reference's [24, 32) pass (same rows, same histogram)
+                launched = true;
+            }
+        }
+        if (launched) { }
+        else if (first && last) { if (vin == nullptr) SWEEP(true, false, false); else SWEEP(false, false, false); }
         else if (first)         { if (vin == nullptr) SWEEP(true, false, true);  else SWEEP(false, false, true); }
         else if (last)          { if (w <= 6) SWEEP_B(false, true, false, 6); else if (w == 7) SWEEP_B(false, true, false, 7); else SWEEP(false, true, false); }   // a narrow top digit:
         else                    SWEEP(false, true, true);                                                                   // fewer digit threads, ballots and status words
+#undef SWEEP_G
 #undef SWEEP_B
 #undef SWEEP
 #ifdef BVH_ABLATION
@@ -474,8 +491,8 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
 }
 
 void sort_pairs(hipStream_t s, const SortScratch& sc, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
-                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {
-    sort_pairs_t<u32>(s, sc, keys_in, vals_in, n, keys_out, vals_out, start_bit, end_bit, hist_ready);
+                uint32_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready, bool gated_narrow_top) {
+    sort_pairs_t<u32>(s, sc, keys_in, vals_in, n, keys_out, vals_out, start_bit, end_bit, hist_ready, gated_narrow_top);
 }
 void sort_pairs64(hipStream_t s, const SortScratch& sc, const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n,
                   uint64_t* keys_out, uint32_t* vals_out, int start_bit, int end_bit, bool hist_ready) {

@@ -386,7 +386,14 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
     if (HIST_BITS > 0) {
         __syncthreads();
         u32* copy = hist + (blockIdx.x % SORT_HIST_COPIES) * SORT_HIST_STRIDE;      // (kernels.hpp: why there are several copies)
-        for (int i = threadIdx.x; i < passes * RADIX; i += EM_BLOCK) { const u32 c = s_hist[i]; if (c) atomicAdd(&copy[i], c); }
+        for (int i = threadIdx.x; i < passes * RADIX; i += EM_BLOCK) {
+            const u32 c = s_hist[i];
+            if (c) {
+                atomicAdd(&copy[i], c);
+                // a code with bit 30 or 31 set (top digit >= 64): the build's sort must take the full-width top pass (SORT_WIDE_FLAG_WORD, kernels.hpp)
+                if (HIST_BITS == 8 && passes == 4 && i >= 3 * RADIX + 64) hist[SORT_WIDE_FLAG_WORD] = 1u;
+            }
+        }
     }
 }
 

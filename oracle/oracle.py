@@ -402,6 +402,9 @@ def ref_driver(nofma: bool = False):
     L.refdrv_generate_rays.argtypes = [vp, vp, u32, u32]
     L.refdrv_trace_while.argtypes = [vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32]
     L.refdrv_trace_kind.argtypes = [C.c_int, vp, vp, u32, vp, u32, vp, vp, vp, u32, u32, u32, u32]
+    L.refdrv_extents.argtypes = [vp, u32, vp, vp]
+    L.refdrv_ploc.argtypes = [vp, u32, vp, vp, vp, C.POINTER(u32), C.c_int]
+    L.refdrv_collapse.argtypes = [C.c_int, vp, vp, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(u32)]
     rc = L.refdrv_init(os.path.join(_HERE, "_ref").encode(), int(nofma))
     if rc != 0:
         raise RuntimeError("refdrv_init: " + L.refdrv_error().decode())
@@ -448,6 +451,35 @@ def ref_hploc(boxes, skeys, svals, nofma=False, cover_all=False):
     nodes = np.zeros(max(n - 1, 1), dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); merged = C.c_uint32()
     _rc(L, L.refdrv_hploc(boxes.ctypes.data, n, skeys.ctypes.data, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, C.byref(merged), int(cover_all)), "refdrv_hploc")
     return nodes[: n - 1], leaves, int(merged.value)
+
+
+def ref_extents(tris, nofma=False):
+    """the reference's CalculateSceneExtents (src/CommonBlocksKernel.h:92-114), its own wave64 flavour, on the GPU -> (Aabb[n], scene Aabb)"""
+    L = ref_driver(nofma); _reinit(L, nofma); n = tris.shape[0]
+    boxes = np.zeros(n, dtype=AABB); scene = np.zeros(1, dtype=AABB)
+    _rc(L, L.refdrv_extents(tris.ctypes.data, n, boxes.ctypes.data, scene.ctypes.data), "refdrv_extents")
+    return boxes, scene
+
+
+def ref_ploc(boxes, svals, nofma=False, never_single_pass=False):
+    """the reference's SetupClusters + Ploc (+ SinglePassPloc below 1024 clusters) kernels, wave64 flavour, on the GPU under the host loop of
+    src/PLOC++Bvh.cpp:82-152 -> (nodes, leaves, iterations)"""
+    L = ref_driver(nofma); _reinit(L, nofma); n = boxes.shape[0]
+    boxes = np.ascontiguousarray(boxes); svals = np.ascontiguousarray(svals, dtype=np.uint32)
+    nodes = np.zeros(n - 1, dtype=BVH2_NODE); leaves = np.zeros(n, dtype=PRIMREF); it = C.c_uint32()
+    _rc(L, L.refdrv_ploc(boxes.ctypes.data, n, svals.ctypes.data, nodes.ctypes.data, leaves.ctypes.data, C.byref(it), int(never_single_pass)), "refdrv_ploc")
+    return nodes, leaves, int(it.value)
+
+
+def ref_collapse(nodes, leaves, root, n, layout, nofma=False):
+    """the reference's CollapseToWide4Bvh kernel (layout 0: src/TwoPassLbvhKernel.h:237-336, layout 1: src/Ploc++Kernel.h:364-465) on the GPU with
+    the reference's host set-up -> (Bvh4Node[n_wide], PrimNode[n], n_wide, leaves placed)"""
+    L = ref_driver(nofma); _reinit(L, nofma)
+    wide = np.zeros(2 * n, dtype=BVH4_NODE); prims = np.zeros(n, dtype=PRIM_NODE); nw = C.c_uint32(); cnt = C.c_uint32()
+    nd = np.ascontiguousarray(nodes); lv = np.ascontiguousarray(leaves) if leaves is not None else None
+    _rc(L, L.refdrv_collapse(layout, nd.ctypes.data, lv.ctypes.data if lv is not None else None, root, n, wide.ctypes.data, prims.ctypes.data,
+                             C.byref(nw), C.byref(cnt)), "refdrv_collapse")
+    return wide[: nw.value].copy(), prims, int(nw.value), int(cnt.value)
 
 
 def ref_generate_rays(camera, width, height, nofma=False):

@@ -6,10 +6,11 @@
 // (src/SinglePassLbvh.cpp:102-131, src/TwoPassLbvh.cpp:99-143, src/Hploc.cpp:83-121, src/PLOC++Bvh.cpp:45-57) — the
 // reference's own host layer needs Orochi, which is not in its tree.
 //
-// What can run on gfx950: every kernel without wave-size assumptions (Morton, both LBVH builders, SetupClusters) and
-// HPloc, whose 32-thread workgroups occupy the lower half of a wave64.  CalculateSceneExtents and Ploc hard-code
-// WarpSize = 32 for cross-lane reductions over larger workgroups (src/Common.h:100-106) and are wrong on wave64 hardware;
-// they are not driven here.
+// What runs on gfx950: every kernel without wave-size assumptions (Morton, both LBVH builders, SetupClusters, both collapse
+// kernels) and HPloc, whose 32-thread workgroups occupy the lower half of a wave64, from the plain builds; CalculateSceneExtents,
+// Ploc and SinglePassPloc — which reduce / scan across a wave with the reference's `WarpSize` constant — from the reference's own
+// WAVE64 flavour of the same unmodified headers (*.w64.co: src/Common.h:100-106 selects WarpSize = 64 under -D__gfx90a__=1,
+// oracle/Makefile).  Round 5; rounds 1-4 wrongly held that these kernels could not run on wave64 hardware.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -20,7 +21,7 @@
 namespace {
 using u32 = uint32_t;
 struct Mod { hipModule_t m = nullptr; };
-Mod g_common, g_single, g_two, g_hploc, g_trav;
+Mod g_common, g_single, g_two, g_hploc, g_trav, g_common64, g_ploc64;
 std::string g_err;
 
 #define RT(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return -(int)e_; } } while (0)
@@ -68,6 +69,8 @@ int refdrv_init(const char* dir, int nofma) {
     TRY(load(g_two, d + "/TwoPassLbvhKernel" + sfx));
     TRY(load(g_hploc, d + "/HplocKernel" + sfx));
     TRY(load(g_trav, d + "/TraversalKernel" + sfx));
+    TRY(load(g_common64, d + "/CommonBlocksKernel.w64" + sfx));
+    TRY(load(g_ploc64, d + "/Ploc++Kernel.w64" + sfx));
     return 0;
 }
 
@@ -125,6 +128,99 @@ int refdrv_hploc(const void* h_boxes, u32 n, const u32* h_skeys, const u32* h_sv
     { void* a[] = { &nodes.p, &leaves.p, &skeys.p, &idx.p, &parent.p, &cnt.p, &ncl, &nint }; TRY(launch(g_hploc.m, "HPloc", cover_all ? n : ni, 32, a)); }
     RT(hipDeviceSynchronize());
     TRY(nodes.down(h_nodes)); TRY(leaves.down(h_leaves)); TRY(cnt.down(merged));
+    return 0;
+}
+
+// CalculateSceneExtents (src/CommonBlocksKernel.h:92-114, wave64 flavour); host: src/PLOC++Bvh.cpp:19-37 (extent reset to +-FltMax, launch over
+// primitiveCount threads in ReductionBlockSize = 256 workgroups)
+int refdrv_extents(const void* h_tris, u32 n, void* h_boxes, void* h_scene) {
+    Dev<B64> tris; Dev<B24> boxes, scene;
+    TRY(tris.alloc(n)); TRY(tris.up(h_tris)); TRY(boxes.alloc(n, 0)); TRY(scene.alloc(1));
+    const float fmax = 3.402823466e+38f; const float ext[6] = { fmax, fmax, fmax, -fmax, -fmax, -fmax };   // Aabb::reset(), src/Common.h:327-331
+    TRY(scene.up(ext));
+    void* a[] = { &tris.p, &boxes.p, &scene.p, &n };
+    TRY(launch(g_common64.m, "CalculateSceneExtents", n, 256, a));
+    RT(hipDeviceSynchronize());
+    TRY(boxes.down(h_boxes)); TRY(scene.down(h_scene));
+    return 0;
+}
+
+// SetupClusters + the host loop of Ploc / SinglePassPloc (src/Ploc++Kernel.h:39-55,98-362, wave64 flavour); host: src/PLOC++Bvh.cpp:82-152 —
+// the three counters are cleared and the merged count read back (D2H) per iteration, the index buffers swap, below PlocBlockSize clusters one
+// SinglePassPloc launch finishes.  *iterations: passes of the loop.  never_single_pass: 0 = the reference's rule (SinglePassPloc below 1024
+// clusters); 1 keeps `Ploc` iterating down to one cluster, which separates the two kernels' behaviour on silicon (a test's instrument).
+int refdrv_ploc(const void* h_boxes, u32 n, const u32* h_svals, void* h_nodes, void* h_leaves, u32* iterations, int never_single_pass) {
+    if (n < 2) { g_err = "n < 2"; return -1; }
+    const u32 ni = n - 1;
+    Dev<B24> boxes; Dev<B32> nodes; Dev<B28> leaves; Dev<u32> svals; Dev<int> idx0, idx1, merged, offsum, counter;
+    TRY(boxes.alloc(n)); TRY(boxes.up(h_boxes)); TRY(nodes.alloc(ni, 0)); TRY(leaves.alloc(n, 0)); TRY(svals.alloc(n)); TRY(svals.up(h_svals));
+    TRY(idx0.alloc(n, 0xFF)); TRY(idx1.alloc(n, 0xFF)); TRY(merged.alloc(1, 0)); TRY(offsum.alloc(1, 0)); TRY(counter.alloc(1, 0));
+    u32 prim = n, nint = ni;
+    { void* a[] = { &nodes.p, &leaves.p, &svals.p, &boxes.p, &idx0.p, &prim }; TRY(launch(g_ploc64.m, "SetupClusters", n, 256, a)); }
+    bool swap = false; u32 c = n, iters = 0;
+    while (c > 1) {
+        RT(hipMemset(merged.p, 0, 4)); RT(hipMemset(offsum.p, 0, 4)); RT(hipMemset(counter.p, 0, 4));
+        int* i0 = !swap ? idx0.p : idx1.p; int* i1 = !swap ? idx1.p : idx0.p;
+        ++iters;
+        if (c < 1024u && !never_single_pass) {                         // PlocBlockSize, src/Common.h:593
+            void* a[] = { &i0, &nodes.p, &leaves.p, &c, &nint };
+            TRY(launch(g_ploc64.m, "SinglePassPloc", c, 1024, a));
+            break;
+        }
+        void* a[] = { &i0, &i1, &nodes.p, &leaves.p, &merged.p, &offsum.p, &counter.p, &c, &nint };
+        TRY(launch(g_ploc64.m, "Ploc", c, 1024, a));
+        int m = 0; RT(hipMemcpy(&m, merged.p, 4, hipMemcpyDeviceToHost));
+        if (m <= 0) { g_err = "Ploc merged nothing"; return -2; }
+        c -= (u32)m; swap = !swap;
+        if (iters > 100000) { g_err = "Ploc does not terminate"; return -3; }
+    }
+    RT(hipDeviceSynchronize());
+    TRY(nodes.down(h_nodes)); TRY(leaves.down(h_leaves));
+    if (iterations) *iterations = iters;
+    return 0;
+}
+
+// CollapseToWide4Bvh — layout 0: src/TwoPassLbvhKernel.h:237-336 (host src/TwoPassLbvh.cpp:154-183); layout 1: src/Ploc++Kernel.h:364-465 (host
+// src/PLOC++Bvh.cpp:154-184).  Task queue all-invalid except the root task, internal-node offset 1, ceil(2 n / 3) threads, all of which must be
+// RESIDENT (the kernel spins until its task appears): the caller keeps n below what the device holds (256-thread workgroups here).
+// h_nodes: layout 0 Bvh2Node[2n-1]; layout 1 Bvh2Node[n-1] (uploaded into a zeroed 2n array: the kernel reads bvh2Nodes[leaf index].m_aabb, :395-396,
+// values unused).  h_wide: Bvh4Node[2n]; h_prims: PrimNode[n]; *n_wide = the internal-node offset after the launch.
+int refdrv_collapse(int layout, const void* h_nodes, const void* h_leaves, u32 root, u32 n, void* h_wide, void* h_prims, u32* n_wide, u32* task_count) {
+    if (n < 2) { g_err = "n < 2"; return -1; }
+    struct B128 { char b[128]; }; struct B8 { char b[8]; };
+    const u32 ni = n - 1;
+    Dev<B32> nodes; Dev<B28> leaves; Dev<B128> wide; Dev<B8> prims; Dev<U2> taskq; Dev<u32> count, offset;
+    const size_t nn = layout == 1 ? 2 * (size_t)n : 2 * (size_t)n - 1;
+    TRY(nodes.alloc(nn, 0)); RT(hipMemcpy(nodes.p, h_nodes, (layout == 1 ? (size_t)ni : nn) * 32, hipMemcpyHostToDevice));
+    if (layout == 1) { TRY(leaves.alloc(n)); TRY(leaves.up(h_leaves)); }
+    TRY(wide.alloc(2 * (size_t)n)); TRY(prims.alloc(n));
+    {   // GpuMemory::reset() is a memset 0 (the structs' INVALID defaults are NOT what the device sees) — src/TwoPassLbvh.cpp:154-155
+        RT(hipMemset(wide.p, 0, 2 * (size_t)n * 128)); RT(hipMemset(prims.p, 0, (size_t)n * 8));
+    }
+    std::vector<U2> q(n, U2{0xFFFFFFFFu, 0xFFFFFFFFu}); q[0] = U2{root, 0xFFFFFFFFu};
+    TRY(taskq.alloc(n)); TRY(taskq.up(q.data()));
+    TRY(count.alloc(1, 0)); TRY(offset.alloc(1)); const u32 one = 1; TRY(offset.up(&one));
+    u32 nint = ni, nleaf = n;
+    const u32 threads = (2 * n + 2) / 3;
+    {   // refuse a launch that cannot be resident as a whole: it would spin for ever (and hang the device)
+        hipFunction_t fn; RT(hipModuleGetFunction(&fn, layout == 1 ? g_ploc64.m : g_two.m, "CollapseToWide4Bvh"));
+        int per_cu = 0, dev = 0, cus = 0;
+        RT(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0));
+        RT(hipGetDevice(&dev)); RT(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if ((size_t)(threads + 255) / 256 > (size_t)per_cu * cus) { g_err = "CollapseToWide4Bvh: grid not resident (" + std::to_string(per_cu) + " x " + std::to_string(cus) + " workgroups)"; return -4; }
+    }
+    if (layout == 1) {
+        void* a[] = { &nodes.p, &leaves.p, &wide.p, &prims.p, &taskq.p, &count.p, &offset.p, &nint, &nleaf };
+        TRY(launch(g_ploc64.m, "CollapseToWide4Bvh", threads, 256, a));
+    } else {
+        void* a[] = { &nodes.p, &wide.p, &prims.p, &taskq.p, &count.p, &offset.p, &nint, &nleaf };
+        TRY(launch(g_two.m, "CollapseToWide4Bvh", threads, 256, a));
+    }
+    RT(hipDeviceSynchronize());
+    TRY(wide.down(h_wide)); TRY(prims.down(h_prims));
+    u32 off = 0, cnt = 0; RT(hipMemcpy(&off, offset.p, 4, hipMemcpyDeviceToHost)); RT(hipMemcpy(&cnt, count.p, 4, hipMemcpyDeviceToHost));
+    if (n_wide) *n_wide = off;
+    if (task_count) *task_count = cnt;
     return 0;
 }
 

@@ -89,9 +89,10 @@ EMU_MESHES = [("cornell", 32, 0), ("cornell", 82, 0), ("cornell", 382, 0), ("uni
 
 @pytest.mark.parametrize("kind,n,seed", EMU_MESHES)
 def test_emulator_matches_hardware_on_hploc(pkg, orc, drv, kind, n, seed):
-    """The instrument check behind the PLOC++ / collapse pins.  The reference's `Ploc` kernel hard-codes wave32 and cannot run on
-    gfx950, so its only executable form is the CPU SIMT emulator (tools/oracle/ref_emulator.cpp) — whose __ballot / __shfl / __syncthreads / LDS atomicMin(u64)
-    / global atomic semantics are this repository's own.  HplocKernel.h speaks the same vocabulary AND runs unmodified on the MI355X: the SAME header under
+    """The instrument check of the CPU SIMT emulator (tools/oracle/ref_emulator.cpp), whose __ballot / __shfl / __syncthreads / LDS
+    atomicMin(u64) / global atomic semantics are this repository's own.  (Rounds 2-4 held the emulator to be the only executable form of the reference's `Ploc`
+    kernel; round 5 runs the reference's own wave64 flavour of it on the MI355X — tests/test_reference_w64.py — and the emulator is now a second, independent
+    reading.)  HplocKernel.h speaks the emulator's vocabulary AND runs unmodified on the MI355X: the SAME header under
     the emulator must build the same tree as on the hardware (contraction off on both sides so that area ties break alike) — same number of merges, same
     leaves, same canonical topology, same SAH."""
     require_ref(os.path.exists(orc.REF_HPLOC_EMU), "oracle/_ref/libref_hploc_emu.so (the reference's HPloc kernel under the CPU emulator)")

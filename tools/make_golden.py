@@ -14,11 +14,16 @@
       (tools/oracle/ref_emulator.cpp, built by oracle/Makefile into oracle/_ref/libref_ploc_emu.so) on the golden meshes and three larger
       ones: FNV-1a of the node array, canonical topology hash, SAH, host-loop iterations — merged into reference_outputs.json under
       "_ploc_emulated"; and of its two CollapseToWide4Bvh kernels (whole grid resident; on the GPU they hang unless every workgroup is) under
-      "_collapse_emulated".  The reference's Ploc kernel cannot run on wave64 hardware, so this is its only executable form here.
+      "_collapse_emulated".  (Rounds 2-4 believed this to be the only executable form of `Ploc` here; step 5 runs the reference's own wave64 flavour on the MI355X.)
   step 4 (anywhere; CPU only, ~1 min):  python tools/make_golden.py fullsize
       The pinned CPU oracle on the configs' own sizes: uniform(10 000 000, seed 1) (config 3: HPLOC; also PLOC++) and uniform(2 000 000, seed 100)
       (config 5's first mesh: HPLOC, PLOC++, single-pass LBVH): canonical topology hash, f64 SAH, FNV-1a of leaves / node array, PLOC++ iterations,
       and the oracle's exact cluster loads / stores / merge calls / NN rounds (the L, S of SURVEY.md §8(d)'s byte formulas) -> "_fullsize".
+  step 5 (GPU box, through gpurun):  python tools/make_golden.py ploc_hw gpurun_out/golden_ploc_hw.json
+      Outputs of the REFERENCE's CalculateSceneExtents / SetupClusters / Ploc / SinglePassPloc / CollapseToWide4Bvh kernels ON THE MI355X — the reference's own
+      wave64 flavour of the unmodified headers (oracle/_ref/*.w64.nofma.co; src/Common.h:100-106 under -D__gfx90a__=1): FNV-1a of boxes / scene extent / leaves,
+      host-loop iterations, canonical BVH2 topology, SAH, number of wide nodes and canonical wide topology of its collapse of its own tree.  Merge the JSON into
+      tests/golden/reference_outputs.json under "_ploc_hw" (python tools/make_golden.py merge_ploc_hw gpurun_out/golden_ploc_hw.json).
 Fixtures are data (inputs and expected outputs); no reference source text is stored.
 """
 import json
@@ -51,6 +56,49 @@ def ploc_meshes(pkg):
     out["sponza40000_s3"] = mg.sponza_like(40000, 3)
     out["bunny30000_s2"] = mg.bunny_like(30000, 2)
     return out
+
+
+def ploc_hw_meshes(pkg):
+    mg = pkg.meshgen
+    out = dict(ploc_meshes(pkg))
+    out["uniform1023_s31"] = mg.uniform(1023, 31); out["uniform1024_s32"] = mg.uniform(1024, 32); out["uniform1025_s33"] = mg.uniform(1025, 33)
+    out["uniform2049_s34"] = mg.uniform(2049, 34)
+    out["sponza262144_s3"] = mg.sponza_like(262_144, 3)        # BASELINE.json config 4's own size
+    return out
+
+
+def ploc_hw_entry(orc, tris):
+    """what the reference's own kernels produce on the MI355X for one mesh (schedule-independent quantities only: node numbering is not)"""
+    n = len(tris)
+    boxes, scene = orc.ref_extents(tris, nofma=True)
+    keys, _ = orc.morton_codes(boxes, scene)
+    order = np.argsort(keys, kind="stable").astype(np.uint32)
+    nodes, leaves, iters = orc.ref_ploc(boxes, order, nofma=True)
+    assert orc.validate_bvh2(nodes, leaves, 0, n, 1) == 0
+    wide, prims, total, placed = orc.ref_collapse(nodes, leaves, 0, n, 1, nofma=True)
+    assert placed == n
+    return {"n": n, "boxes_fnv": "%016x" % orc.fnv1a(boxes), "scene_fnv": "%016x" % orc.fnv1a(scene), "ploc_iterations": iters,
+            "ploc_leaves_fnv": "%016x" % orc.fnv1a(leaves), "ploc_topology": "%016x" % orc.topology_hash(nodes, leaves, 0, n, 1),
+            "ploc_sah_f64": round(orc.sah_bvh2(nodes, leaves, 0, n, 1)[0], 9),
+            "collapse_n_wide": total, "collapse_topology4": "%016x" % orc.topology_hash4(wide, prims, total, n)}
+
+
+def make_ploc_hw(out_path):
+    import bvh_pkg
+    import oracle as orc
+    pkg = bvh_pkg.load()
+    out = {}
+    for name, tris in ploc_hw_meshes(pkg).items():
+        out[name] = ploc_hw_entry(orc, tris)
+        print(name, out[name], flush=True)
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+
+
+def merge_ploc_hw(in_path):
+    path = os.path.join(GOLDEN, "reference_outputs.json")
+    res = json.load(open(path)); res["_ploc_hw"] = json.load(open(in_path))
+    json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 
 
 def make_ploc():
@@ -174,6 +222,10 @@ if __name__ == "__main__":
         make_meshes()
     elif len(sys.argv) >= 2 and sys.argv[1] == "ploc":
         make_ploc()
+    elif len(sys.argv) >= 3 and sys.argv[1] == "ploc_hw":
+        make_ploc_hw(sys.argv[2])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "merge_ploc_hw":
+        merge_ploc_hw(sys.argv[2])
     elif len(sys.argv) >= 3 and sys.argv[1] == "reference":
         make_reference(sys.argv[2])
     else:
