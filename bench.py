@@ -327,14 +327,20 @@ def main() -> None:
         if rk:                                                      # the same fraction from the rocprofv3 kernel-trace average (all launches of the profiled run, warm-up included)
             roof["frac_rocprof"] = round(alg_bytes / max(launches_per_build, 1.0) / (rk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if name == "k_onesweep" else round(alg_bytes / (rk["avg_us"] * 1e-6 * max(launches_per_build, 1.0)) / 1e9 / HBM_PEAK_GBS, 4)
             roof["rocprof_avg_us"] = rk["avg_us"]; roof["profiles_match_kernel_sources"]["rocprof"] = rp.get("_kernel_source_hash") == src_hash
-        # the second bound: VALU / LDS pipe occupancy of this kernel from the committed SQ counters (profiles/issue_counters.json, written by
-        # tools/prof_round.sh from a rocprofv3 --pmc pass of this command; recompute: insts x cycles_per_inst / (units x launch cycles))
+        # what the waves of this kernel do with their cycles, straight from the committed SQ counters (profiles/issue_counters.json, a rocprofv3 --pmc pass of this
+        # command): no priced estimates (round 4 printed a "VALU busy" that multiplied instruction counts with micro-benchmarked cycle costs; the in-situ probes and the
+        # occupancy sweep of profiles/r05_att_hploc_block.md bound that figure to 0.62-0.72 and show that no pipe is what the launch waits for)
         ic = (_load_json("issue_counters.json") or {}).get(f"{name}@{n}")
         if ic:
             cyc = ic["SQ_BUSY_CYCLES"] / ic["shader_engines"]                                    # launch length in shader cycles
-            roof["issue"] = {"valu_busy_frac": round(ic["SQ_INSTS_VALU"] * ic["cycles_per_valu_inst"] / (ic["simds"] * cyc), 4),
-                             "lds_busy_frac": round(ic["SQ_INSTS_LDS"] * ic["cycles_per_lds_inst"] / (ic["cus"] * cyc), 4),
-                             "waves_parked_frac": round(ic["SQ_WAIT_ANY"] / ic["SQ_WAVE_CYCLES"], 4), "source": "profiles/issue_counters.json (priced estimate: instructions x measured cycles per instruction)"}
+            wc = ic["SQ_WAVE_CYCLES"]
+            roof["issue"] = {"waves_parked_frac": round(ic["SQ_WAIT_ANY"] / wc, 4),                    # at s_waitcnt / barriers: the dependent chain
+                             "waves_ready_not_issued_frac": round(ic["SQ_WAIT_INST_ANY"] / wc, 4),    # lost arbitration / pipe busy
+                             "waves_issuing_frac": round(ic["SQ_ACTIVE_INST_ANY"] / wc, 4),
+                             "valu_issue_slots_used_frac": round(ic["SQ_INSTS_VALU"] * 4.0 / (ic["simds"] * cyc), 4),   # one VALU instruction per SIMD quad-cycle = 1.0 (an upper bound on VALU busy)
+                             "resident_waves_per_simd": round(wc * 4.0 / (ic["simds"] * cyc), 2),
+                             "bound": "dependent chain of the PLOC rounds at the residency cap of 8 waves per SIMD (profiles/r05_att_hploc_block.md)",
+                             "source": "profiles/issue_counters.json (direct SQ counter ratios)"}
             roof["profiles_match_kernel_sources"]["issue_counters"] = (_load_json("issue_counters.json") or {}).get("_kernel_source_hash") == src_hash
         if name in KERNEL_OWN_BYTES_PER_PRIM:     # the same kernel against the bytes it really has to move (work lists stay in LDS)
             own = KERNEL_OWN_BYTES_PER_PRIM[name] * n

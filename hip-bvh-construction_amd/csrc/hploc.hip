@@ -482,7 +482,8 @@ struct WaveList {            // k_hploc_ext: a wave's two 32-slot work lists wit
 template <bool AGENT, bool IL, typename List, bool WIDE = false>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
                                                 const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
-                                                u32 below = 0u) {
+                                                u32 below = 0u, u32* rclk = nullptr) {
+    // rclk (measurement build, ABL_ROUND_CLOCK): wave-uniform sums {wave-rounds, shader-clock ticks spent in them, active halves} — tools/round_clock.py
     typename List::Tag tag = tag_io;
     u32 cnt = cnt_io;
     Box b = b_io;
@@ -491,6 +492,9 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
     // a task that needs no round only left-packs its right child's clusters (done up front: a helping half's b does not survive the loop, HPB_WIDE)
     if (have && cnt <= threshold && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);
     while (__ballot(have && cnt > threshold)) {
+#ifdef ABL_ROUND_CLOCK
+        const u64 rc_t0 = __builtin_amdgcn_s_memtime();
+#endif
 #if HPB_NO_HOIST
         asm volatile("" : "+v"(slot));          // the eight `slot + r` of the search are recomputed every round instead of living in eight registers across the loop
 #endif
@@ -577,6 +581,13 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
         { u32 x = (u32)nn[(__float_as_uint(b.lx) >> 29) + (u32)(lane & 56)];
           asm volatile("" : "+v"(x));
           if (x == 0x12345u) cnt = 0u; }
+#endif
+#ifdef ABL_ROUND_CLOCK
+        if (rclk) {
+            asm volatile("" : "+v"(b.lx), "+v"(tag));                     // (the round's read-back has landed when the clock is read)
+            const u64 am2 = __ballot(act);
+            rclk[0] += 1u; rclk[1] += (u32)(__builtin_amdgcn_s_memtime() - rc_t0); rclk[2] += ((u32)am2 != 0u ? 1u : 0u) + ((u32)(am2 >> 32) != 0u ? 1u : 0u);
+        }
 #endif
     }
     tag_io = tag; cnt_io = cnt; b_io = b;
@@ -1031,6 +1042,13 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                          //    has big children.  Waves walk their static share of the level-sorted task list in order, so whatever a task waits for sits EARLIER in some
                          //    wave's sequence: no cycle.  A wave's LDS operations execute in order: the survivors a task wrote are in LDS before its arrival count is.
     // (only the non-empty levels are visited — ~5 of 64: a scan over s_cnt cost a dependent LDS read per empty level)
+#ifdef ABL_ROUND_CLOCK    // measurement build (tools/round_clock.py): how long a PLOC round takes a wave INSIDE the launch, how many of a wave's level-loop ticks are rounds
+    u32 rclk[3] = { 0u, 0u, 0u };
+    u32* const rclk_p = rclk;
+    const u64 rc_loop0 = __builtin_amdgcn_s_memtime();
+#else
+    u32* const rclk_p = nullptr;
+#endif
     u64 lvm[2];
     for (int i = 0; i < 2; ++i) { const u64 m = s_lvmask[i]; lvm[i] = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(m >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)m); }
     for (int lw = 0; lw < (NLEV + 63) / 64; ++lw)
@@ -1077,7 +1095,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false, HPB_IL != 0, TileList, (HPB_WIDE != 0 && HPB_IL == 0)>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below);
+            ploc_rounds_lds<false, HPB_IL != 0, TileList, (HPB_WIDE != 0 && HPB_IL == 0)>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below, rclk_p);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
 #if HPB_DEPS
             if (have && slot == 0) {                 // tell the parent, if it is a task of this tile
@@ -1105,6 +1123,13 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
 #if HPB_DEPS
     __syncthreads();
+#endif
+#ifdef ABL_ROUND_CLOCK
+    if (lane == 0) {     // per wave, into the sub-queue's padded head (words 20..24; cleared with the queue heads by every build's first kernel)
+        u32* out = q_count + sub * 32u + 20u;
+        atomicAdd(out + 0, rclk[0]); atomicAdd(out + 1, rclk[1]); atomicAdd(out + 2, rclk[2]);
+        atomicAdd(out + 3, (u32)(__builtin_amdgcn_s_memtime() - rc_loop0)); atomicAdd(out + 4, 1u);
+    }
 #endif
 #if HPB_PRIO == 1 || HPB_PRIO == 2
     __builtin_amdgcn_s_setprio(0);

@@ -1,12 +1,8 @@
 #!/usr/bin/env python3
 """profiles/issue_counters.json from a rocprofv3 --pmc pass (SQ counters only) of bench.py: per kernel the per-launch averages that bench.py turns into
-roofline.issue = {valu_busy_frac, lds_busy_frac, waves_parked_frac}:
-    valu_busy_frac = SQ_INSTS_VALU x cycles_per_valu_inst / (simds x SQ_BUSY_CYCLES / shader_engines)
-    lds_busy_frac  = SQ_INSTS_LDS  x cycles_per_lds_inst  / (cus   x SQ_BUSY_CYCLES / shader_engines)
-cycles_per_*_inst: the instruction mix of the kernel's PLOC round (profiles/r03_hploc_bound.md section 3, round-3 loop) priced with the measured
-per-kind costs of profiles/r03_ubench_issue.md — VALU (scalar neighbour search): (48 DPP moves + 54 min/max + 13 compares) x 4.1 + (72 sub/mul/add + 17 moves) x 2.2
-+ ~40 others x 3.3 over ~244 = 3.3 cycles; LDS (round-3 tile kernel): 148 LDS-pipe cycles over 32 instructions = 4.6 cycles.  These are saturated-pipe prices:
-the in-situ probes of profiles/r03_hploc_bound.md show the VALUs are not the limiter, so valu_busy_frac is an upper estimate.
+roofline.issue — direct ratios only since round 5 (waves parked / ready but not issued / issuing as fractions of SQ_WAVE_CYCLES, VALU issue slots used =
+SQ_INSTS_VALU x 4 / (simds x launch cycles), resident waves per SIMD).  The file still carries the round-3 prices (cycles_per_*_inst: the round's instruction mix
+priced with profiles/r03_ubench_issue.md) for the record; bench.py no longer multiplies with them: profiles/r05_att_hploc_block.md shows they over-state VALU busy.
 Usage: tools/issue_counters.py <results.db> <n_tris> [out.json]"""
 import json
 import sqlite3
