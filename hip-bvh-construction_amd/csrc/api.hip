@@ -71,8 +71,6 @@ struct bvh_ctx {
     hipEvent_t ev[8] = {};
     int scene_slot = 0;               // which of the two scene extents the next build uses
     bool scene_ready = false;         // that extent holds Aabb::reset values (written by the previous build's Morton kernel); false: reset it explicitly
-    uint32_t ploc_epoch = 0;          // epoch base of the next resident PLOC++ launch (its exchange words are compared for equality: every launch gets fresh values)
-    uint32_t ploc_last_resident = 0;  // iterations the resident launch of the last PLOC++ build ran (0: it did not run)
     uint32_t ploc_last_n = 0, ploc_last_iters = 0;   // size and iteration count of the last PLOC++ build (run_ploc aims its first batch of launches at it)
     u32* h_pinned = nullptr;          // pinned, device-accessible host words: the small read-backs (root index, PLOC++ state, collapse level counts) land here as {v, ~v} pairs
     u32* d_pinned = nullptr;          // the same words as the device addresses them
@@ -115,9 +113,6 @@ inline int herr(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 // sentinel" — ADVICE r03 —, and round 4 caught that copy landing byte by byte: see misc.hip).  Acquire loads: nothing read afterwards can be hoisted above the poll.  The
 // stream is in order, so everything enqueued before the read-back kernel is complete when the pairs are.  Bounded: after ~4 M rounds it falls back to hipStreamSynchronize,
 // which also surfaces an error of the stream.
-#ifndef BVH_POLL_READBACK
-#define BVH_POLL_READBACK 1
-#endif
 static int wait_readback(hipStream_t s, const u32* pairs, u32 count) {
     auto all_landed = [&]() -> bool {
         for (u32 i = 0; i < count; ++i) {
@@ -126,14 +121,12 @@ static int wait_readback(hipStream_t s, const u32* pairs, u32 count) {
         }
         return true;
     };
-#if BVH_POLL_READBACK
     for (u32 polls = 0; polls < (1u << 22); ++polls) {
         if (all_landed()) return 0;
 #if defined(__x86_64__)
         __builtin_ia32_pause();                      // (be a polite spinner: the runtime's helper threads may share this core)
 #endif
     }
-#endif
     HIP_TRY(hipStreamSynchronize(s));
     return all_landed() ? 0 : BVH_E_INTERNAL;
 }
@@ -178,7 +171,6 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->ploc.ids1 = k.take<u32>(n);
     c->ploc.status = k.take<u64>((size_t)PLOC_MAX_ITERS * ploc_chunks(cap));
     c->ploc.state = k.take<u32>(PLOC_STATE_WORDS);
-    c->ploc.xchg = k.take<char>(ploc_xchg_bytes());
     c->small = k.take<u32>(64);            // [0] root, [1] hploc zero-parent, [8..9] f64 SAH / BVH4 cost, [10..11] u64 checksum, [16..31] camera, [32..47] transform, [48..57] Morton plan read-back
     c->hploc.zero_parent = c->small + 1;
     *total = k.off;
@@ -197,8 +189,6 @@ int ensure_capacity(bvh_ctx* c, uint32_t n) {
     carve(c, p, n, &total);
     HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)n * sizeof(u64), c->stream));   // HPLOC dependency words: clean once, builds keep them clean
     HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)n * sizeof(u32), c->stream));    // two-pass LBVH exchange words: likewise
-    HIP_TRY(hipMemsetAsync(c->ploc.xchg, 0, ploc_xchg_bytes(), c->stream));         // PLOC++ resident launch: epoch words (they only ever grow)
-    c->ploc_epoch = 0;
     return 0;
 }
 
@@ -240,28 +230,17 @@ static int read_back(bvh_ctx* c, const u32* d_a, u32 na, const u32* d_b, u32 nb,
 // PLOC++ iteration driver: batches of device-side iterations, one small read-back per batch (src/PLOC++Bvh.cpp:132-152
 // reads back after EVERY iteration).
 int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const u32* d_svals, const PlocScratch& sc, uint32_t* iterations_out) {
-    // lists of 4..256 chunks CAN run their first iterations in ONE cooperative launch with the list resident in LDS (ploc.hip k_ploc_resident; same trees)
-    // — measured SLOWER than the per-iteration launches (Sponza-like 262 144: 0.4706 vs 0.3919 ms; the all-to-all exchange of 256 workgroups through global memory costs more
-    // than a launch boundary: DESIGN.md section 9 row 61), so it only runs when the host asks for it (BVH_OPT_PLOC_SCHEDULER = 2)
-    bool resident = false;
-    if (c->options[BVH_OPT_PLOC_SCHEDULER] == 2) {
-        if (c->ploc_epoch > 0xFFFF0000u) { HIP_TRY(hipMemsetAsync(sc.xchg, 0, ploc_xchg_bytes(), c->stream)); c->ploc_epoch = 0; }
-        resident = ploc_resident(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, c->ploc_epoch);
-        if (resident) c->ploc_epoch += 2u * (u32)PLOC_MAX_ITERS;
-    }
     u32* const host_state = c->h_pinned + 16;                // (pinned: the per-batch read-back does not go through a staging buffer)
     constexpr size_t state_bytes = PLOC_STATE_WORDS * sizeof(u32);
     u32 iters_before = 0;                                    // iterations counted before the bookkeeping was last restarted (a restart clears the device's counter)
-    int first = resident ? 1 : 0, parity = 0;
-    bool fresh = !resident;
+    int first = 0, parity = 0;
+    bool fresh = true;
     // iterations needed grow by ~3 per doubling of n (measured: 30 at 262 k, 45 at 10 M); the first batch aims slightly above
     // (round 2: 30 at 262 k, 34 at 2 M, 40 at 10 M on uniform meshes — two more per doubling; a launch after the end still costs ~5 us)
     int batch = 32; for (uint32_t m = n; m > 262144u; m >>= 1) batch += 2; if (batch > 80) batch = 80;
     // rebuilds of a scene of the same size (animation frames; the benchmark loop) need the same number of iterations give or take one: aim one above the
     // previous build's count instead of two to four (an iteration launched after the end costs ~5 us; one short costs a read-back and a second batch)
     if (c->ploc_last_n == n && c->ploc_last_iters > 0 && c->ploc_last_iters + 1 < PLOC_MAX_ITERS) batch = (int)c->ploc_last_iters + 1;
-    // (the resident launch ran some of those iterations itself: as many as last time, give or take)
-    if (resident) { const int ran = c->ploc_last_n == n && c->ploc_last_resident > 0 ? (int)c->ploc_last_resident : 10; batch = batch > ran + 4 ? batch - ran + 1 : 5; }
     // every iteration merges at least the globally closest pair, so n iterations always suffice (a collinear, zero-area scene needs
     // almost that many: every union has area 0 and only the lowest pair of a chunk is mutual); the reference loops the same way
     for (uint32_t guard = 0; guard < n / 16u + 4096u; ++guard) {
@@ -275,15 +254,15 @@ int run_ploc(bvh_ctx* c, uint32_t n, void* d_nodes, void* d_leaves, const void* 
             ploc_reset(c->stream, sc, n, count);
             first = 0;
         }
-        ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh, resident ? (int)(c->ploc_last_n == n && c->ploc_last_resident ? c->ploc_last_resident : 10u) - 1 : 0);
+        ploc_enqueue(c->stream, sc, n, d_nodes, d_leaves, d_boxes, d_svals, first, batch, parity, fresh);
         fresh = false;
-        // three words come back: the iterations done so far, those of them the resident launch ran, and the cluster count after this batch (pairs at pinned words 4..9)
+        // two words come back: the iterations done so far and the cluster count after this batch (pairs at pinned words 4..7)
         u32* const rb = c->h_pinned + 4;
-        { const int wr = read_back(c, sc.state + 2 * PLOC_MAX_ITERS + 1, 2, sc.state + first + batch, 1, rb); if (wr) return wr; }
-        const u32* const h_iters = rb; const u32* const h_count = rb + 4;
+        { const int wr = read_back(c, sc.state + 2 * PLOC_MAX_ITERS + 1, 1, sc.state + first + batch, 1, rb); if (wr) return wr; }
+        const u32* const h_iters = rb; const u32* const h_count = rb + 2;
         const u32 count = *h_count;
         if (count <= 1) {
-            c->ploc_last_n = n; c->ploc_last_iters = iters_before ? 0u : *h_iters; c->ploc_last_resident = resident ? rb[2] : 0u;
+            c->ploc_last_n = n; c->ploc_last_iters = iters_before ? 0u : *h_iters;
             if (iterations_out) *iterations_out = iters_before + *h_iters;
             return 0;
         }
@@ -329,7 +308,7 @@ int bvh_ctx_set_option(bvh_ctx* c, bvh_option option, int64_t value) {
     if (!c) return BVH_E_INVALID_ARG;
     switch (option) {
         case BVH_OPT_HPLOC_SCHEDULER: case BVH_OPT_LBVH_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
-        case BVH_OPT_PLOC_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_PLOC_SCHEDULER: if (value < 0 || value > 1) return BVH_E_INVALID_ARG; break;
         case BVH_OPT_SORT_TEST_KNOBS: if (value & ~(int64_t)(8 | 32)) return BVH_E_INVALID_ARG; break;
         default: return BVH_E_INVALID_ARG;
     }
@@ -590,11 +569,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
     // M: CalculateMortonCodes (token CalculateMortonCodesTime); values are implicit (value i = i), produced by sort pass 0
     if (key_bits == 64) launch_morton64(s, c->boxes, n, scene, reinterpret_cast<u64*>(c->keys), 60, c->sort.hist, passes, scene_next);
-#ifdef MORTON_P0_ROWS   // (cost probe: the rows land in pass 0's status rows as flag-less counts, which the owners overwrite)
-    else launch_morton(s, c->boxes, n, scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes, scene_next, n >= SORT_WIDE_MIN_N ? c->sort.status : nullptr);
-#else
     else launch_morton(s, c->boxes, n, scene, c->keys, nullptr, c->sort.hist, SORT_BITS, passes, scene_next);
-#endif
     if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
     // S: radix sort (token SortingTime)
     if (key_bits == 64) sort_pairs64(s, c->sort, reinterpret_cast<const u64*>(c->keys), nullptr, n, reinterpret_cast<u64*>(c->skeys), c->svals, 0, end_bit, true);

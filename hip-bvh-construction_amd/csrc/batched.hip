@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <chrono>
 #include <new>
+#include <cstring>
 #include <thread>
 #include <vector>
 #include "bvh_mi355x.h"
@@ -127,6 +128,8 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
             }
         }
     }
+    // slots without a mesh (n_meshes is not a multiple of the device count) gather zeros, not a previous call's boxes (blocking, before any lane starts: ADVICE r04)
+    for (int d = 0; d < n_dev; ++d) if (hipSetDevice(b->devs[d]) != hipSuccess || hipMemset(b->d_send[d], 0, (size_t)slots * 6 * sizeof(float)) != hipSuccess) return BVH_E_INTERNAL;
     std::atomic<int> err{0};
     auto fail = [&](int code) { int z = 0; err.compare_exchange_strong(z, code); };
     // ---- builds: one host thread per (device, lane); device d's k-th mesh (m = d + k * n_dev) runs on lane k % lanes
@@ -134,6 +137,9 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
     for (int d = 0; d < n_dev; ++d) for (int l = 0; l < lanes; ++l) th.emplace_back([&, d, l]() {
         bvh_ctx* c = b->lane(d, l);
         if (hipSetDevice(b->devs[d]) != hipSuccess) return fail(BVH_E_INTERNAL);
+        // whatever way this lane leaves (its own error, another lane's), nothing of it is still in flight when bvh_batch_build returns: the next call may free and
+        // re-allocate the output arena its copies write into
+        struct Drain { bvh_ctx* c; ~Drain() { (void)bvh_ctx_synchronize(c); } } drain{c};
         bvh_ctx_set_profiling(c, rep->build_ms ? 1 : 0);
         for (int k = l; d + k * n_dev < n_meshes; k += lanes) {
             if (err.load()) return;
@@ -142,10 +148,6 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
             int rc2 = bvh_build(c, algo, h_tris[m], n_tris[m], 0, &r, &t); if (rc2) return fail(rc2);
             if (rep->build_ms) rep->build_ms[m] = t.ms_total;
             if (r.root >= tree_nodes(algo, n_tris[m]) || !r.d_nodes) {
-#ifdef BATCH_DEBUG
-                uint32_t again = 0; (void)bvh_ctx_synchronize(c); (void)bvh_dev_download(c, &again, (const char*)r.d_sorted_keys, 4);
-                fprintf(stderr, "batch: mesh %d lane %d n %u root %u (0x%x) key0 %u\n", m, l, n_tris[m], r.root, r.root, again);
-#endif
                 return fail(BVH_E_INTERNAL);      // (never trust an index that is about to become an address)
             }
             // root AABB = nodes[root].aabb (24 bytes at offset 8 of the 32-byte node)
@@ -165,6 +167,7 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
     });
     for (auto& t : th) t.join();
     rc = err.load();
+    if (rc && rep->meshes) std::memset(rep->meshes, 0, sizeof(bvh_batch_mesh) * (size_t)n_meshes);      // (no pointer into a half-written tree survives a failed call)
     // ---- the only collective: all-gather of the root-AABB slots (every lane's stream has been synchronised: the slots are written)
     if (!rc) {
         // RCCL enqueues the collective's kernels at ncclGroupEnd, not at the ncclAllGather call inside the group: the events that bracket it are

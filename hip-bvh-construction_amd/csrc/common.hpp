@@ -54,26 +54,14 @@ __device__ __forceinline__ float hi_f(u64 v) { return __uint_as_float((u32)(v >>
 // one per byte on this chip (MI355X_MICROARCH.md, stores table).  Inline asm: hipcc has no builtin for a 16-byte global store
 // with the sc1 bit; the trailing s_nop keeps the data registers alive until the store has read them (guide §5.7 item 1),
 // completion is awaited by drain_stores() before the publishing atomic, as for every other agent-scope store.
-#ifndef BVH_NODE_STORE_X4
-#define BVH_NODE_STORE_X4 1
-#endif
 __device__ __forceinline__ void node_store_agent(bvh2_node* n, u32 left, u32 right, const Box& b) {
-#if BVH_NODE_STORE_X4
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f q0 = { __uint_as_float(left), __uint_as_float(right), b.lx, b.ly };
     const v4f q1 = { b.lz, b.hx, b.hy, b.hz };
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
                  :: "v"(n), "v"(q0), "v"(q1) : "memory");
-#else
-    u64* q = reinterpret_cast<u64*>(n);
-    st_agent(q + 0, (u64)left | ((u64)right << 32));
-    st_agent(q + 1, pack2(b.lx, b.ly));
-    st_agent(q + 2, pack2(b.lz, b.hx));
-    st_agent(q + 3, pack2(b.hy, b.hz));
-#endif
 }
 __device__ __forceinline__ Box node_box_agent(const bvh2_node* n) {
-#if BVH_NODE_STORE_X4
     // two 16-byte sc1 loads (8-byte agent-scope accesses run at 0.54-0.70x the 16-byte rate); the wait is part of the
     // statement because hipcc does not count loads issued from inline asm (guide §5.7 item 1, form (i))
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -81,11 +69,6 @@ __device__ __forceinline__ Box node_box_agent(const bvh2_node* n) {
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(q0), "=&v"(q1) : "v"(n) : "memory");
     return { q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
-#else
-    const u64* q = reinterpret_cast<const u64*>(n);
-    const u64 a = ld_agent(q + 1), b = ld_agent(q + 2), c = ld_agent(q + 3);
-    return { lo_f(a), hi_f(a), lo_f(b), hi_f(b), lo_f(c), hi_f(c) };
-#endif
 }
 // a whole 32-byte record {w0, w1, box} (Bvh2Node layout) written by node_store_agent, possibly by another workgroup of this launch
 __device__ __forceinline__ void rec_load_agent(const bvh2_node* n, u32& w0, u32& w1, Box& b) {
@@ -107,13 +90,9 @@ __device__ __forceinline__ void rec_wait(rec_v4f& q0, rec_v4f& q1) { asm volatil
 __device__ __forceinline__ void node_box_store_agent(bvh2_node* n, const Box& b) {
     u64* q = reinterpret_cast<u64*>(n);
     st_agent(q + 1, pack2(b.lx, b.ly));
-#if BVH_NODE_STORE_X4
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f q1 = { b.lz, b.hx, b.hy, b.hz };
     asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(n), "v"(q1) : "memory");
-#else
-    st_agent(q + 2, pack2(b.lz, b.hx)); st_agent(q + 3, pack2(b.hy, b.hz));
-#endif
 }
 // whole node, plain (cached) stores: two 16-byte writes
 __device__ __forceinline__ void node_store_plain(bvh2_node* n, u32 left, u32 right, const Box& b) {
@@ -131,18 +110,11 @@ __device__ __forceinline__ Box box_load(const bvh_aabb* p) {
 }
 // the gather form (one random 24-byte record per lane): a 16-byte + an 8-byte load instead of three 8-byte ones — the record is 8-byte aligned and a multi-dword
 // global load only needs dword alignment, so the texture-address unit sees two lane requests per box instead of three
-#ifndef BVH_GATHER_X4
-#define BVH_GATHER_X4 1
-#endif
 __device__ __forceinline__ Box box_gather(const bvh_aabb* p) {
-#if BVH_GATHER_X4
     typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
     const f4a8 a = *reinterpret_cast<const f4a8*>(p);
     const float2 c = reinterpret_cast<const float2*>(p)[2];
     return { a.x, a.y, a.z, a.w, c.x, c.y };
-#else
-    return box_load(p);
-#endif
 }
 // the bounds of a 64-byte Triangle record, with stage E's operations in stage E's order (stage_em.hip k_extents): the same bits as the box array holds
 __device__ __forceinline__ Box tri_box_gather(const float4* t) {

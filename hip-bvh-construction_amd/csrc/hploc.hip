@@ -123,13 +123,6 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
     return w;
 }
 
-#ifndef HP_NN_SCALAR
-#define HP_NN_SCALAR 1     // 1 (default since round 3): nn_search evaluates one candidate per step with scalar f32 operations — fewer live registers (the tile kernel
-                           //    no longer spills at 7 waves per SIMD) and each pair's atomics leave as soon as its area exists: tile kernel 0.714 -> 0.67 ms; 0: two per step, packed f32
-#endif
-#ifndef HP_NN_BF
-#define HP_NN_BF 0         // A/B switch: 1 = no branches around the candidates of nn_search (HP_NN_LDS = 3 only)
-#endif
 #ifndef HP_NN_LDS
 #define HP_NN_LDS 3        // neighbour selection.  3 (default since round 4): the pair's key is minimised into the FAR end's word by an LDS atomic (the reference's formulation) and into
                            //    the lane's own running minimum by ONE v_min_f64 on the same 64-bit key (eight LDS atomics per round instead of sixteen; k_hploc_ext 0.200 -> 0.195 ms,
@@ -145,12 +138,8 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
 // nn: the wave's 64-entry LDS scratch.  ABL_*: in-situ cost probes of tools/ab_probe.sh (wrong trees, timing only; profiles/r03_hploc_bound.md).
 template <bool PUBLISH = false>
 __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int lane, int slot, u64* nn) {
-#if HP_NN_LDS
     nn[lane] = ~0ull;
     compiler_fence();                        // reset, atomics and read-back stay in program order
-#if HP_NN_LDS == 2
-    u32 abR = 0xFFFFFFFFu; int idR = 0;      // the lane's own right-hand candidates: running minimum in registers (strict <: lowest slot on equal areas)
-#endif
 #if HP_NN_LDS == 3
     // the lane's own right-hand candidates: the SAME 64-bit key {area bits, other end's slot}, minimised in a register pair by v_min_f64 — one VALU instruction
     // instead of one LDS atomic.  An area is a non-negative f32, so the key read as an f64 is a non-negative finite number (its exponent field is the area's
@@ -158,89 +147,24 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
     // compared, not flushed (the f64 denormal mode of every HIP kernel is "preserve"), and a minimum returns one of its operands bit for bit.
     double own = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
 #endif
-#else
-    // two running minima instead of one 64-bit key: right candidates arrive with increasing slot (strict < keeps the lower slot on ties), left
-    // candidates with decreasing slot (<= takes the lower slot), left beats right on ties
-    u32 abR = 0xFFFFFFFFu, abL = 0xFFFFFFFFu; int idR = 0, idL = 0;
-    const int la = lane << 2;
-#endif
-#if HP_NN_SCALAR && HP_NN_LDS >= 1 && !defined(ABL_NO_ATOMIC)
     // one candidate per step, scalar f32 (a packed f32 operation costs what two scalar ones do on gfx950 — profiles/r03_ubench_issue.md — and the
     // two-candidate form keeps twelve more registers alive): the same operations in the same association
     Box nb = b;
 #pragma unroll
     for (int rr = 1; rr <= HP_RADIUS; ++rr) {
-#ifndef ABL_NO_DPPMOV
         nb = box_shl1(nb);                                                       // box of slot + rr
-#endif
         const float ex = fmaxf(nb.hx, b.hx) - fminf(nb.lx, b.lx), ey = fmaxf(nb.hy, b.hy) - fminf(nb.ly, b.ly), ez = fmaxf(nb.hz, b.hz) - fminf(nb.lz, b.lz);
         const float half_area = ex * ey + ex * ez + ey * ez;                     // Aabb::area (:361-365): 2 * (xy + xz + yz)
         const u32 ab = __float_as_uint(half_area + half_area);                   // (x + x == 2 * x exactly)
-#if HP_NN_BF && HP_NN_LDS == 3
-        // branch-free (tile kernel only: its key words have eight spare ones behind the last wave's): a pair that does not exist sends all ones to the far end's
-        // word (never wins; lanes 56..63 reach into the next wave's first words) and the largest finite key to the own minimum
-        const bool valid = act && (u32)(slot + rr) < cnt;
-        if (PUBLISH) {
-            atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)(valid ? ab : 0xFFFFFFFFu) << 32) | (u32)slot);
-            own = __builtin_fmin(own, __longlong_as_double((long long)(((unsigned long long)(valid ? ab : 0x7FEFFFFFu) << 32) | (u32)(slot + rr))));
-        }
-        if (!PUBLISH && valid) {
-#else
         if (act && (u32)(slot + rr) < cnt) {                                     // both ends are clusters of this task
-#endif
             atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
-#if HP_NN_LDS == 2
-            if (ab < abR) { abR = ab; idR = slot + rr; }
-#elif HP_NN_LDS == 3
+#if HP_NN_LDS == 3
             own = __builtin_fmin(own, __longlong_as_double((long long)(((unsigned long long)ab << 32) | (u32)(slot + rr))));
 #else
             atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
 #endif
         }
     }
-#else
-    Box nb = b;
-    typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int r = 1; r <= HP_RADIUS; r += 2) {
-#ifdef ABL_NO_DPPMOV
-        const Box n1 = nb, n2 = nb;
-#else
-        const Box n1 = box_shl1(nb);                                     // box of slot + r
-        const Box n2 = box_shl1(n1);                                     // box of slot + r + 1
-#endif
-        nb = n2;
-        const v2f lx = { fminf(n1.lx, b.lx), fminf(n2.lx, b.lx) }, ly = { fminf(n1.ly, b.ly), fminf(n2.ly, b.ly) }, lz = { fminf(n1.lz, b.lz), fminf(n2.lz, b.lz) };
-        const v2f hx = { fmaxf(n1.hx, b.hx), fmaxf(n2.hx, b.hx) }, hy = { fmaxf(n1.hy, b.hy), fmaxf(n2.hy, b.hy) }, hz = { fmaxf(n1.hz, b.hz), fmaxf(n2.hz, b.hz) };
-        const v2f ex = hx - lx, ey = hy - ly, ez = hz - lz;
-        const v2f half_area = ex * ey + ex * ez + ey * ez;               // Aabb::area (:361-365): 2 * (xy + xz + yz)
-        const v2f area = half_area + half_area;                          // (x + x == 2 * x exactly)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int rr = r + q;
-            const u32 ab = __float_as_uint(q ? area.y : area.x);
-#if defined(ABL_NO_ATOMIC)
-            (void)ab; (void)rr;
-#elif HP_NN_LDS == 1
-            if (act && (u32)(slot + rr) < cnt) {                         // both ends are clusters of this task
-                atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
-                atomicMin(reinterpret_cast<unsigned long long*>(nn + lane), ((unsigned long long)ab << 32) | (u32)(slot + rr));
-            }
-#elif HP_NN_LDS == 2
-            // the pair's key goes to the FAR end's word only (an LDS instruction costs the tile kernel ~6 VALU instructions: profiles/r03_hploc_bound.md);
-            // the near end keeps its own candidates in registers
-            if (act && (u32)(slot + rr) < cnt) {
-                atomicMin(reinterpret_cast<unsigned long long*>(nn + lane + rr), ((unsigned long long)ab << 32) | (u32)slot);
-                if (ab < abR) { abR = ab; idR = slot + rr; }
-            }
-#else
-            const u32 ab_left = (u32)__builtin_amdgcn_ds_bpermute(la + (256 - 4 * rr), (int)ab);   // area(slot - rr, slot)
-            if ((u32)(slot + rr) < cnt && ab < abR) { abR = ab; idR = slot + rr; }
-            if (slot >= rr && (u32)slot < cnt && ab_left <= abL) { abL = ab_left; idL = slot - rr; }
-#endif
-        }
-    }
-#endif
     int probe = 0;
 #ifdef ABL_EXTRA_BPERM   // 8 more LDS crossbar operations per round
 #pragma unroll
@@ -252,15 +176,9 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
       for (int e = 0; e < 48; ++e) acc = fminf(acc * 1.0000001f, dpp_shl1(acc) + b.ly);
       probe ^= (int)__float_as_uint(acc); }
 #endif
-#if defined(ABL_NO_ATOMIC)
-    return (slot ^ 1) | (probe == 0x7fffabcd ? 64 : 0);
-#elif HP_NN_LDS == 1
+#if HP_NN_LDS == 1
     compiler_fence();
     return (int)(u32)nn[lane] | (probe == 0x7fffabcd ? 64 : 0);
-#elif HP_NN_LDS == 2
-    compiler_fence();
-    const u64 left = nn[lane];               // minimum over the pairs (slot - r, slot): lower slots, so it wins on equal areas
-    return ((u32)(left >> 32) <= abR ? (int)(u32)left : idR) | (probe == 0x7fffabcd ? 64 : 0);
 #elif HP_NN_LDS == 3
     compiler_fence();
     const u64 left = nn[lane];               // minimum over the pairs (slot - r, slot), or all ones
@@ -272,7 +190,7 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
     }
     return (int)choice | (probe == 0x7fffabcd ? 64 : 0);
 #else
-    return ((abL <= abR) ? idL : idR) | (probe == 0x7fffabcd ? 64 : 0);
+#error "HP_NN_LDS is 3 (default) or 1"
 #endif
 }
 
@@ -300,55 +218,12 @@ __device__ __forceinline__ int nn_search_wide(const Box& b, Box nb, u32 off, u32
     return (int)(u32)nn[lane];
 }
 
-// The same search for the tile kernel's INTERLEAVED lane layout (HPB_IL): lanes 0..15 of a half hold the task's even slots, lanes 16..31 the odd ones, and
-// every lane also holds o = the box of slot + 1 (read from the LDS list together with its own record).  The box of slot + r is then a 16-lane ROW shift of
-// b (r even: by r / 2) or of o (r odd: by (r - 1) / 2; r = 1: o itself) — a DPP operand of the union's v_min / v_max, no data movement: the 48 v_mov_b32_dpp of
-// the wave_shl chain are gone.  A shift that leaves the row reads 0; such a pair has slot + r >= 32 >= cnt and is masked.  nnh: the half's 32 (+ 8) key words, by slot.
-#ifndef HP_IL_MASKED
-#define HP_IL_MASKED 0
-#endif
-#if HP_IL_MASKED
-#define HP_IL_ATOMICS(RR) const u32 ab = __float_as_uint(half_area + half_area); \
-        if (act && (u32)(slot + (RR)) < cnt) { \
-            atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot + (RR)), ((unsigned long long)ab << 32) | (u32)slot); \
-            atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot), ((unsigned long long)ab << 32) | (u32)(slot + (RR))); }
-#else
-#define HP_IL_ATOMICS(RR) const u32 ab = (act && (u32)(slot + (RR)) < cnt) ? __float_as_uint(half_area + half_area) : 0xFFFFFFFFu; \
-        atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot + (RR)), ((unsigned long long)ab << 32) | (u32)slot); \
-        atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot), ((unsigned long long)ab << 32) | (u32)(slot + (RR)));
-#endif
-#define HP_IL_CAND(RR, SRC, K) { \
-        const Box n_ = (K) == 0 ? (SRC) : row_shl<((K) == 0 ? 1 : (K))>(SRC); \
-        const float ex = fmaxf(n_.hx, b.hx) - fminf(n_.lx, b.lx), ey = fmaxf(n_.hy, b.hy) - fminf(n_.ly, b.ly), ez = fmaxf(n_.hz, b.hz) - fminf(n_.lz, b.lz); \
-        const float half_area = ex * ey + ex * ez + ey * ez; \
-        /* no branch around the atomics: a pair that does not exist sends the key's high word as all ones, which never wins a minimum (and an address */ \
-        /* beyond the half's words is only ever "minimised" with that).  With a branch the compiler sinks the union into it, and the DPP operand */ \
-        /* cannot follow (cross-lane reads need the full EXEC mask): the row shifts would stay separate v_mov_b32_dpp */ \
-        HP_IL_ATOMICS(RR) }
-// o is read from the list HERE (position opos) and used by the odd distances, which come after the even ones: the read's latency hides under four
-// candidates, and o is not alive across the merge / compaction part of the round (that is what made the first version of this layout spill).
-template <typename List>
-__device__ __forceinline__ int nn_search_il(const Box& b, const List& list, u32 opos, bool act, u32 cnt, int slot, u64* nnh) {
-    nnh[slot] = ~0ull;
-    const Box o = list.load_box(opos);
-    compiler_fence();
-    HP_IL_CAND(2, b, 1) HP_IL_CAND(4, b, 2) HP_IL_CAND(6, b, 3) HP_IL_CAND(8, b, 4)
-    HP_IL_CAND(1, o, 0) HP_IL_CAND(3, o, 1) HP_IL_CAND(5, o, 2) HP_IL_CAND(7, o, 3)
-    compiler_fence();
-    return (int)(u32)nnh[slot];
-}
-#undef HP_IL_CAND
-#undef HP_IL_ATOMICS
-
 // PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
 // registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
 // read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
 // nn: the wave's 64-entry LDS scratch for the nearest-neighbour keys (nn_search)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // hook: called at the end of every round (the measurement builds count rounds there; tools/probes/hploc_ext_lookahead_wide.patch consumed an early load)
-#ifndef HPX_NO_HOIST
-#define HPX_NO_HOIST 0
-#endif
 template <bool AGENT = true, typename Hook = NoHook>
 __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* zero_parent, u32 ni, int lane, int slot, int hbase, u64* nn, Hook hook = Hook()) {
         const bool have = w.have, final_ = w.final_;
@@ -356,9 +231,6 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
         Box b = w.b;
         const u32 threshold = final_ ? 1u : HP_HALF;
         while (__ballot(have && cnt > threshold)) {
-#if HPX_NO_HOIST
-            asm volatile("" : "+v"(slot));      // the eight `slot + r` of the search are recomputed every round instead of living in eight registers across the kernel's loop
-#endif
             const bool act = have && cnt > threshold;
             const int nbr = nn_search(b, act, cnt, lane, slot, nn);
             // mergeClusters (:126-190)
@@ -368,13 +240,9 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             const bool mutual = in && nbr_of_nbr == (u32)slot;
             const bool merge = mutual && slot < nbr;
             const bool absorbed = mutual && slot > nbr;
-#ifdef ABL_NO_BPERM
-            const u32 id_nb = id + 1u, rep_nb = rep + 1u; const Box bn = b;
-#else
             const u32 id_nb = (u32)__shfl((int)id, nsrc);
             const u32 rep_nb = (u32)__shfl((int)rep, nsrc);
             const Box bn = shfl_box(b, nsrc);
-#endif
             if (merge) {
                 b = box_union(b, bn);
                 u32 at = rep_nb - 1u;                            // the absorbed partner's rep is retired here, once
@@ -403,13 +271,9 @@ __device__ __forceinline__ void ploc_rounds(HpWork& w, bvh2_node* nodes, u32* ze
             const u32 kh = (u32)(__ballot(keep) >> hbase);
             const u32 newcnt = (u32)__popc(kh);
             const int dst = act ? (hbase + (keep ? (int)__popc(kh & ((1u << slot) - 1u)) : 31)) : lane;
-#ifdef ABL_NO_PERMUTE
-            id = id + (u32)dst; rep = rep ^ 1u;
-#else
             id = push_u32(dst, id); rep = push_u32(dst, rep);
             b.lx = push_f32(dst, b.lx); b.ly = push_f32(dst, b.ly); b.lz = push_f32(dst, b.lz);
             b.hx = push_f32(dst, b.hx); b.hy = push_f32(dst, b.hy); b.hz = push_f32(dst, b.hz);
-#endif
             if (act) { if ((u32)slot >= newcnt) id = INV; cnt = newcnt; }
             hook();
         }
@@ -478,25 +342,21 @@ struct WaveList {            // k_hploc_ext: a wave's two 32-slot work lists wit
 };
 // One task per 32-lane half.  In: have / final_ (uniform per half), cnt, and the lane's cluster (tag, b; invalid beyond cnt) as loaded from the list.
 // Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
-// IL: interleaved lane layout (nn_search_il): slot is NOT lane & 31; below = the half's lanes that hold lower slots; o_in = box of slot + 1.
-template <bool AGENT, bool IL, typename List, bool WIDE = false>
+template <bool AGENT, typename List, bool WIDE = false>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
                                                 const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
-                                                u32 below = 0u, u32* rclk = nullptr) {
+                                                u32* rclk = nullptr) {
     // rclk (measurement build, ABL_ROUND_CLOCK): wave-uniform sums {wave-rounds, shader-clock ticks spent in them, active halves} — tools/round_clock.py
     typename List::Tag tag = tag_io;
     u32 cnt = cnt_io;
     Box b = b_io;
-    if (!IL) below = (1u << slot) - 1u;
+    const u32 below = (1u << slot) - 1u;                  // the half's lanes that hold lower slots
     const u32 threshold = final_ ? 1u : HP_HALF;
     // a task that needs no round only left-packs its right child's clusters (done up front: a helping half's b does not survive the loop, HPB_WIDE)
     if (have && cnt <= threshold && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);
     while (__ballot(have && cnt > threshold)) {
 #ifdef ABL_ROUND_CLOCK
         const u64 rc_t0 = __builtin_amdgcn_s_memtime();
-#endif
-#if HPB_NO_HOIST
-        asm volatile("" : "+v"(slot));          // the eight `slot + r` of the search are recomputed every round instead of living in eight registers across the loop
 #endif
         const bool act = have && cnt > threshold;
         u32 nbr;
@@ -515,9 +375,7 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
             b = list.load_box(p0 < lim ? p0 : lim);
             const Box st = list.load_box(p1 < lim ? p1 : lim);
             nbr = (u32)nn_search_wide(b, st, off, a_cnt, ah + slot, slot, lane, nn) & 31u;
-        } else
-        if (IL) { const u32 p1 = (u32)slot + 1u < nl ? base + (u32)slot + 1u : rbase + (u32)slot + 1u; nbr = (u32)nn_search_il(b, list, p1 < lim ? p1 : lim, act, cnt, slot, nn + hbase) & 31u; }
-        else {
+        } else {
             const u32 raw = (u32)nn_search<true>(b, act, cnt, lane, slot, nn);
             nbr = raw & 31u;
 #if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_BPERM)     // (keeps nn_search's in-situ probes alive in the tile kernel: the mask above would let the compiler drop them)
@@ -727,48 +585,17 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
     constexpr int NLEV = KeyBits<K>::value;          // hierarchy levels = bits of the augmented key (64 / 96)
     constexpr int KM = 18;                           // key margin: the hand-over probes up to 17 leaves beyond the tile's rims (small children of external
-#ifndef HPB_IL
-#define HPB_IL 0         // 1: interleaved lane layout of the tile kernel's rounds (nn_search_il: the row shifts become DPP operands of v_min / v_max, 48 fewer VALU
-                         //    instructions per round).  Measured (round 3): 0.72 vs 0.66 ms while the box of slot + 1 stayed alive across the round (6 spilled registers); read
-                         //    at the start of the search instead (no spill, 70 VGPRs): 0.664 vs 0.666 ms — the DPP moves are not on the critical path.  Kept for A/B.
-#endif
-#ifndef HPB_NO_HOIST
-#define HPB_NO_HOIST 0       // A/B switch (off).  1: 49 VGPRs instead of 64 (the eight hoisted `slot + r` go), but 0.5873 -> 0.5968 ms: the registers buy nothing while LDS holds the
-#endif                     //    kernel at eight workgroups per CU; with HPB_WIDE on top (58 VGPRs, no spill) 0.5897 — the whole-wave lone rounds give back what the recomputation costs
-#ifndef HPB_SEARCH_BOTH
-#define HPB_SEARCH_BOTH 0     // A/B switch (off: 0.5825 vs 0.5870 ms — the pre-loop phases of a tile are not what the kernel waits for, tools/tile_phases.py)
-#endif
-#ifndef HPB_STAGE_SERIAL_GATHER
-#define HPB_STAGE_SERIAL_GATHER 1   // 1: a thread's PER box gathers go out one after the other (0: together — measured slower at 10 M, see the staging)
-#endif
 #ifndef HPB_WIDE
 #define HPB_WIDE 0       // A/B switch (off: measured, no gain — DESIGN.md section 9 row 64).  1: a round in which only one half of the wave still has a task runs that task on the whole wave (nn_search_wide: four candidates per lane)
 #endif
-#ifndef HPB_PREPROBE
-#define HPB_PREPROBE 1   // 1: two probes at p - 8 / p + 9 decide most gaps before the binary searches for a node's range (the searches run compacted, one gap per thread)
-#endif
-#ifndef HPB_PAIR_SORT
-#define HPB_PAIR_SORT 1  // 1: a level's tasks are ordered by size class before they are dealt to the waves' halves
-#endif
-#ifndef HPB_PRIO
-#define HPB_PRIO 0       // A/B switch (off): s_setprio in the tile kernel — 1: a level's waves run at a priority that grows as the level thins out (<= 2 tasks: 3, <= 4: 2,
-#endif                   //    <= 8: 1); 2: the whole level loop above staging / ranges / hand-over; 3: staging and ranges above the level loop.  Measured: DESIGN.md section 9
-#ifndef HPB_LEAN
-#define HPB_LEAN 1       // 1 (default since round 4): 20.3 KB of LDS instead of 22.9 — EIGHT workgroups per CU: the key window shares its storage with the rounds' key words and is
-#endif                   //    re-read for the hand-over; level counters sized for the key type.  Round 3 measured it slower (eight waves per SIMD allow 64 VGPRs and the kernel
                          //    needed 70: spills in the rounds); since the rounds no longer keep a task's box and tag alive for a store behind the loop (ploc_rounds_lds: the
                          //    left-pack of a task that needs no round runs up front; 70 -> 66 VGPRs, tile kernel 0.644 -> 0.633 ms by itself) the kernel fits 64 registers with
                          //    two spilled: 10 M 0.6396 -> 0.6255 ms, 2 M 0.158 -> 0.1535 (production flags, three runs each; HPB_OCC = 8 goes with it)
-#if HPB_LEAN
     constexpr int NLV = NLEV;
     constexpr size_t KN_BYTES = sizeof(K) * (T + 2 * KM) > sizeof(u64) * (NT + 8) ? sizeof(K) * (T + 2 * KM) : sizeof(u64) * (NT + 8);
     __shared__ u64 s_kn[(KN_BYTES + 7) / 8];
     K* const s_key = reinterpret_cast<K*>(s_kn);
     u64 (* const s_nn)[WAVE] = reinterpret_cast<u64 (*)[WAVE]>(s_kn);
-#else
-    constexpr int NLV = 128;
-    __shared__ K s_key[T + 2 * KM];                  // nodes) — with the margin in LDS none of them is a dependent global load; positions g0-KM .. g0+T+KM-1
-#endif
     // work lists: per position the cluster's id and rep, tile-relative in 16 bits (a cluster merged inside the tile absorbs a
     // partner whose first leaf lies in the tile, so node index = rep' - 1 is tile-local too), and its box (SoA)
     __shared__ u32 e_ir[T];                          // id | rep << 16, tile-relative (TileList)
@@ -781,10 +608,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ u64 s_lvmask[2];                      // the non-empty levels (bit lv of word lv / 64): the level loop visits only those
     __shared__ u32 s_npub, s_nready, s_qbase, s_ncand;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
-#if !HPB_LEAN
-    __shared__ u64 s_nnf[NT + 8];                    // per wave: 64 nearest-neighbour key words of the PLOC rounds (+ 8: nn_search_il's unmasked atomics of the last
-    u64 (* const s_nn)[WAVE] = reinterpret_cast<u64 (*)[WAVE]>(s_nnf);   //   wave's highest slots reach 8 words further; they carry all-ones keys and change nothing)
-#endif
 #ifdef ABL_LDS_PAD       // in-situ probe: fewer workgroups per CU (is the kernel bound by latency x occupancy?)
     __shared__ u32 s_pad[ABL_LDS_PAD / 4];
     if (tid_x() == 0 && n == 0xFFFFFFFFu) s_pad[bid_x() % (ABL_LDS_PAD / 4)] = 1u;
@@ -808,9 +631,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     const u32 sub = bid_x() % HPQ_SUB;
     const TileList tl{ e_ir, e_b0, e_b1, e_b2, g0, ni };
 
-#if HPB_PRIO == 3
-    __builtin_amdgcn_s_setprio(2);
-#endif
     // ---- stage the block: leaves (SetupClusters :44-47, fused), keys -------------------------------------------------
     // Every load of a dependency level is issued before the first one is waited for: the key window and the PER primitive indices together, then the PER box gathers.
     // (Indices are clamped, not branched around: with a branch per leaf the compiler emitted index -> wait -> box -> wait per leaf and then the key window one load
@@ -838,9 +658,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             box_[i] = box_gather(boxes + prim_[i]);
-#if HPB_STAGE_SERIAL_GATHER
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(box_[i].lx), "+v"(box_[i].ly), "+v"(box_[i].lz), "+v"(box_[i].hx), "+v"(box_[i].hy), "+v"(box_[i].hz) :: "memory");
-#endif
         }
     }
 #pragma unroll
@@ -858,15 +676,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             e_b0[k] = make_float2(b.lx, b.ly); e_b1[k] = make_float2(b.lz, b.hx); e_b2[k] = make_float2(b.hy, b.hz);
         }
     }
-#ifdef ABL_DOUBLE_STAGE   // in-situ probe: the tile's gather a second time (other leaves), nothing stored: is the staging exposed or hidden under other tiles' rounds?
-    {   float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const u32 k = (u32)tid + (u32)i * NT;
-            if (k < nleaf) { const u32 g = (g0 + k + n / 2u) % n; const Box b = box_load(boxes + svals[g]); acc += b.lx + b.ly + b.lz + b.hx + b.hy + b.hz; }
-        }
-        if (__float_as_uint(acc) == 0x7fffabcdu) e_ir[0] = 0u; }
-#endif
     if (tid < NLV) s_cnt[tid] = 0u;
     if (tid == 0) { s_npub = 0u; s_nready = 0u; s_ncand = 0u; }
     __syncthreads();
@@ -880,13 +689,8 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     const int jmax = (g0 + (u32)T <= ni) ? (int)(g0 + (u32)T) : (int)ni;
     auto wkey = [&](int j) -> K { return s_key[j - (int)g0 + KM]; };
     int my_lv[PER]; u32 my_pos[PER], my_gap[PER];
-#if HPB_PAIR_SORT
     u32 my_cls[PER];
     auto lv_total = [](u32 w) -> u32 { return (w & 63u) + ((w >> 6) & 63u) + ((w >> 12) & 63u) + ((w >> 18) & 63u) + ((w >> 24) & 63u); };
-#else
-    auto lv_total = [](u32 w) -> u32 { return w; };
-#endif
-#if HPB_PREPROBE
     // Only ~9 % of the gaps are merge tasks, another few per cent are lopsided small nodes or sit near a rim of the tile, yet the two binary searches below cost
     // ~160 VALU instructions per gap: two probes at p - 8 and p + 9 first — neither inside means the node spans at most [p - 7, p + 8], 16 leaves, inside the
     // tile: no task, not external — and only the gaps that survive are compacted (s_task is free until the level sort) and searched, one per thread.
@@ -905,17 +709,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
     __syncthreads();
     const u32 ncand = s_ncand;
-#endif
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-#if HPB_PREPROBE
         const u32 ci = (u32)tid + (u32)i * NT;
         const bool on = ci < ncand;
         const u32 k = on ? (u32)s_task[ci] : 0u;
-#else
-        const u32 k = (u32)tid + (u32)i * NT;
-        const bool on = k < nleaf && g0 + k < ni;
-#endif
         const u32 pc = g0 + k;
         my_lv[i] = -1; my_pos[i] = 0; my_gap[i] = k;
         if (on) {
@@ -926,25 +724,12 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             // the positions sharing the node's prefix are contiguous around p: plain binary searches over the window for the two
             // ends (a fixed ~log2(T) probes per side; an exponential search costs the wave its longest lane: ~2x as many)
             int lo = p, hi = p + 1;
-#if HPB_SEARCH_BOTH
-            {   // both ends in the same loop: a step's two probes are independent LDS reads (one round trip instead of two; round 4: 18 -> ~9 dependent reads per gap)
-                int la = jmin, lb = p;                                           // first inside position in [jmin, p]
-                int ha = p + 1, hb = jmax;                                       // last inside position in [p+1, jmax]
-                while (la < lb || ha < hb) {
-                    const int lm = (la + lb) >> 1, hm = (ha + hb + 1) >> 1;
-                    const bool il = inside(lm), ih = inside(hm);
-                    if (la < lb) { if (il) lb = lm; else la = lm + 1; }
-                    if (ha < hb) { if (ih) ha = hm; else hb = hm - 1; }
-                }
-                lo = la; hi = ha; }
-#else
             {   int a = jmin, b = p;                                             // first inside position in [jmin, p]
                 while (a < b) { const int mid = (a + b) >> 1; if (inside(mid)) b = mid; else a = mid + 1; }
                 lo = a; }
             {   int a = p + 1, b = jmax;                                         // last inside position in [p+1, jmax]
                 while (a < b) { const int mid = (a + b + 1) >> 1; if (inside(mid)) a = mid; else b = mid - 1; }
                 hi = a; }
-#endif
             const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
             m_range[k] = 0u;
             if (ext) {
@@ -963,19 +748,12 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 const u32 gl = (u32)lo, gr = (u32)hi;
                 const u32 pq = parent_gap(gl, gr, ni, [&](u32 a, u32 b2) { return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b2), b2, wkey((int)b2 + 1), b2 + 1u); });
                 m_range[k] = (u32)(lo - (int)g0) | (pq == gr ? 0u : 0x8000u) | ((u32)(hi - (int)g0) << 16);
-#ifdef ABL_SKIP_ABOVE    // in-situ probe: local nodes of more than ABL_SKIP_ABOVE leaves are not run at all (what would the tile kernel cost without its thin upper levels?)
-                if ((u32)(hi - lo + 1) > (u32)ABL_SKIP_ABOVE) continue;
-#endif
                 my_lv[i] = NLEV - 1 - c0;
-#if HPB_PAIR_SORT
                 // the level's tasks are grouped by size class (6-bit counters packed in the level's word: at most T / 17 <= 60 disjoint tasks per level), so that
                 // the two tasks of a wave pass need about the same number of rounds (a pass lasts as long as the longer of its two tasks)
                 const u32 sz = (u32)(hi - lo + 1);
                 my_cls[i] = sz > 32u ? 4u : (sz - 17u) >> 2;
                 my_pos[i] = (atomicAdd(&s_cnt[my_lv[i]], 1u << (6u * my_cls[i])) >> (6u * my_cls[i])) & 63u;
-#else
-                my_pos[i] = atomicAdd(&s_cnt[my_lv[i]], 1u);
-#endif
             }
         }
     }
@@ -988,7 +766,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     }
     __syncthreads();
 #pragma unroll
-#if HPB_PAIR_SORT
     for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) {
         const u32 w = s_cnt[my_lv[i]];
         const u32 before = lv_total(w & ((1u << (6u * my_cls[i])) - 1u));            // tasks of the lower classes on this level
@@ -1002,14 +779,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         if (lane == 0) s_lvmask[wave] = m;
     }
     __syncthreads();
-#else
-    for (int i = 0; i < PER; ++i) if (my_lv[i] >= 0) s_task[s_off[my_lv[i]] + my_pos[i]] = (unsigned short)my_gap[i];
-    if (tid < 128) { const u64 m = __ballot(tid < NLV && s_cnt[tid < NLV ? tid : 0] != 0u); if (lane == 0) s_lvmask[wave] = m; }
-    __syncthreads();
-#endif
-#if HPB_DEPS
-    static_assert(!HPB_LEAN, "HPB_DEPS needs the key window during the level loop");
-#endif
     TILE_PHASE(2);
     if (dbg == 2) return;
 #ifdef BVH_ABLATION       // measurement build: merge tasks run by the tile kernel (word 2 of sub-queue 0's padded head; read through BVH_OPT_DEBUG_TASKS_LOCAL)
@@ -1017,28 +786,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #endif
 
     // ---- local hierarchy, deepest level first; two tasks per wave pass ----------------------------------------------------
-#if HPB_PRIO == 2
-    __builtin_amdgcn_s_setprio(2);
-#elif HPB_PRIO == 3
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#ifndef HPB_ROT
-#define HPB_ROT 0        // 1: the wave that takes a level's first task pair rotates with the tile index.  A workgroup's wave w runs on SIMD w of its CU (four waves, dealt
-#endif                   //    round-robin), and a thin level (<= 2 tasks: the top of every tile's hierarchy) only occupies the first wave: without the rotation the thin levels of
                          //    all seven resident tiles queue on ONE SIMD while the other three idle.  Measured (round 4): the premise is wrong — tools/probes/simd_map.hip
                          //    shows the hardware starts every workgroup's round-robin on the next SIMD (wave 0 lands on each SIMD a quarter of the time) — and the
                          //    switch changes nothing (0.6500 / 0.6515 vs 0.6511 / 0.6495 ms).  Off.
-#if HPB_ROT
-    const u32 wrot = ((u32)wave + bid_x()) & (u32)(NW - 1);
-#else
     const u32 wrot = (u32)wave;
-#endif
-#ifndef HPB_DEPS_SLEEP
-#define HPB_DEPS_SLEEP 2 // (x 64 cycles between two polls of a waiting wave)
-#endif
-#ifndef HPB_DEPS
-#define HPB_DEPS 0       // 1: no barrier between the levels of a tile's hierarchy — a task starts as soon as its own big children have finished.  Every finished task adds 1
-#endif                   //    to bits 30..31 of its parent's m_range word (if the parent is a local task); a task waits (s_sleep) until its word shows as many arrivals as it
                          //    has big children.  Waves walk their static share of the level-sorted task list in order, so whatever a task waits for sits EARLIER in some
                          //    wave's sequence: no cycle.  A wave's LDS operations execute in order: the survivors a task wrote are in LDS before its arrival count is.
     // (only the non-empty levels are visited — ~5 of 64: a scan over s_cnt cost a dependent LDS read per empty level)
@@ -1057,24 +808,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
         lvm[lw] &= lvm[lw] - 1ull;
         const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)s_cnt[lv]);             // (block-uniform: the deal below is scalar arithmetic and a scalar loop)
         const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)s_off[lv]);
-#if HPB_PRIO == 1
-        if (c <= 2u) __builtin_amdgcn_s_setprio(3); else if (c <= 4u) __builtin_amdgcn_s_setprio(2); else if (c <= 8u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
         for (u32 tw = wrot * 2u; tw < c; tw += (u32)NW * 2u) {
             const u32 t = tw + (u32)half;
             const bool have = t < c;
             u32 P = 0, L = 0, R = 0;
             if (have) { P = s_task[base + t]; const u32 rg = m_range[P]; L = rg & 0x3FFFu; R = (rg >> 16) & 0x3FFFu; }
-#if HPB_DEPS
-            {   const u32 need = have ? ((P - L + 1u > HP_HALF ? 1u : 0u) + (R - P > HP_HALF ? 1u : 0u)) : 0u;
-                while (true) {
-                    const u32 got = have ? (__hip_atomic_load(&m_range[P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 30) : 0u;
-                    if (!__ballot(have && got != need)) break;
-                __builtin_amdgcn_s_sleep(HPB_DEPS_SLEEP);
-                }
-                compiler_fence();                    // the list reads below stay behind the poll
-            }
-#endif
             // loadIndices (:192-206) from the LDS work lists: the first <= 16 valid entries of each child range, left-packed on the fly; the rounds
             // run on the list in place and leave the survivors at the range's first positions (storeIndices :208-218)
             const bool is_left = slot < 16;
@@ -1085,33 +823,14 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb >> 16);
             u32 cnt = nl + nr;
             const u32 rbase = P + 1u - nl;
-#if HPB_IL
-            const int ts = ((lane & 15) << 1) | ((lane >> 4) & 1);                               // the task slot this lane holds (interleaved layout: nn_search_il)
-            const u32 below = ((1u << ((lane & 15) + ((lane >> 4) & 1))) - 1u) | (((1u << (lane & 15)) - 1u) << 16);
-#else
-            const int ts = slot; const u32 below = 0u;
-#endif
+            const int ts = slot;
             const u32 sp = (u32)ts < nl ? L + (u32)ts : rbase + (u32)ts;
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false, HPB_IL != 0, TileList, (HPB_WIDE != 0 && HPB_IL == 0)>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], below, rclk_p);
+            ploc_rounds_lds<false, TileList, HPB_WIDE != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], rclk_p);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
-#if HPB_DEPS
-            if (have && slot == 0) {                 // tell the parent, if it is a task of this tile
-                const u32 gL = g0 + L, gR = g0 + R;
-                if (!(gL == 0u && gR == ni)) {
-                    const u32 q = parent_gap(gL, gR, ni, [&](u32 a, u32 b2) {   // both pairs lie inside the key window (margin KM)
-                        return plen(wkey((int)a), a, wkey((int)a + 1), a + 1u) > plen(wkey((int)b2), b2, wkey((int)b2 + 1), b2 + 1u); });
-                    if (q >= g0 && q - g0 < (u32)T) {
-                        const u32 pr = __hip_atomic_load(&m_range[q - g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (!m_is_ext(pr) && pr != 0u) { compiler_fence(); atomicAdd(&m_range[q - g0], 1u << 30); }
-                    }
-                }
-            }
-#endif
         }
-#if !HPB_DEPS
 #if defined(ABL_TILE_PHASES) && ABL_TILE_PHASES >= 2     // (2: also the waits at the levels' barriers — two more stamps per level)
         const u64 ph_b0 = __builtin_amdgcn_s_memtime();
         __syncthreads();
@@ -1119,20 +838,13 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #else
         __syncthreads();
 #endif
-#endif
     }
-#if HPB_DEPS
-    __syncthreads();
-#endif
 #ifdef ABL_ROUND_CLOCK
     if (lane == 0) {     // per wave, into the sub-queue's padded head (words 20..24; cleared with the queue heads by every build's first kernel)
         u32* out = q_count + sub * 32u + 20u;
         atomicAdd(out + 0, rclk[0]); atomicAdd(out + 1, rclk[1]); atomicAdd(out + 2, rclk[2]);
         atomicAdd(out + 3, (u32)(__builtin_amdgcn_s_memtime() - rc_loop0)); atomicAdd(out + 4, 1u);
     }
-#endif
-#if HPB_PRIO == 1 || HPB_PRIO == 2
-    __builtin_amdgcn_s_setprio(0);
 #endif
     TILE_PHASE(3);
     if (dbg == 3) return;
@@ -1228,9 +940,6 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
 #ifdef ABL_EXT_TRACE     // measurement build: the tasks of more than n / 4096 leaves leave {start, end (100 MHz clock), range, hand-over taken} in the unused tail of the queue buffer
 __device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap, u64 t0, u32 L, u32 R, u32 ni, u32 kind, u32 nrounds, u64 t_loaded = 0, u64 t_rounds = 0, u64 t_done = 0) {
     if ((R - L + 1u) <= (ni + 1u) / 4096u) return;
-#ifdef EXT_TRACE_NOP
-    return;
-#endif
     const u32 at = atomicAdd(trace_count, 1u);
     // e[3]: kind | rounds << 8 | (ticks from the pass's start to "work list loaded") << 16 | (... to "rounds done") << 32 (100 MHz ticks, 16 bits each)
     if (at < cap) { u64* e = trace + (size_t)at * 4u; e[0] = t0; e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = (u64)L | ((u64)R << 32);
@@ -1243,11 +952,6 @@ __device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap,
 #define EXT_TRACE_ARGS
 #define EXT_TRACE_PASS
 #endif
-#ifndef HPX_LDS_LIST
-#define HPX_LDS_LIST 0   // 1: k_hploc_ext's rounds run on a per-wave work list in LDS (ploc_rounds_lds, as in the tile kernel); 0 (default): register lists + crossbar
-                         //    (ploc_rounds).  Measured (round 3, trees equal): 10 M 0.229 vs 0.213 ms, 2 M 0.097 vs 0.0945 — here the list has to be written and read back around
-                         //    every task (in the tile kernel it lives in LDS anyway), and the kernel needs 100 instead of 90 VGPRs
-#endif
 struct ExtCarry { u32 id, rep; Box b; int side; };    // a half's survivors after a task (slot = lane & 31 < 16); side (owner lane): 0 none, 1 = they are
                                                       // the LEFT child of the half's next task, 2 = the RIGHT child
 template <typename K>
@@ -1259,9 +963,6 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
 #endif
 #ifdef ABL_EXT_TIMING    // measurement build: where a pass spends its cycles and which hand-over it takes (words 3.. of sub-queue 0's padded head; tools/ext_timing.py)
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef ABL_EXT_STOP_ABOVE   // in-situ probe: nodes of more than n / ABL_EXT_STOP_ABOVE leaves are not run (how much of k_hploc_ext is the chain at the top of the tree?)
-    if (ready && (R - L + 1u) > (ni + 1u) / (u32)ABL_EXT_STOP_ABOVE) { ready = false; cw.side = 0; st_agent(dep + pc, 0ull); }
 #endif
     const bool have = __shfl((int)ready, hbase) != 0;
     const u32 tL = (u32)__shfl((int)L, hbase), tR = (u32)__shfl((int)R, hbase), tP = (u32)__shfl((int)pc, hbase);
@@ -1307,21 +1008,12 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     u32 nrounds = 0;
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, [&]() { ++nrounds; });
     const u64 t2 = __builtin_amdgcn_s_memrealtime();
-#elif defined(ABL_EXT_TRACE) && !defined(EXT_TRACE_NOHOOK)
+#elif defined(ABL_EXT_TRACE)
     asm volatile("" : "+v"(w.b.lx), "+v"(w.id));                            // (the list is in registers before the stamp)
     const u64 tr1 = __builtin_amdgcn_s_memrealtime();
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn, [&]() { ++tr_rounds; });
     asm volatile("" : "+v"(w.b.lx), "+v"(w.id));
     const u64 tr2 = __builtin_amdgcn_s_memrealtime();
-#elif HPX_LDS_LIST
-    {   // the rounds run on the half's list in LDS (ploc_rounds_lds: the partner is read, survivors are written to their rank — no crossbar operations,
-        // ~50 fewer VALU instructions per round); the list is filled from the left-packed registers and the survivors are read back into them
-        WaveList::Tag tag = WaveList::make(w.id, w.rep);
-        wl.store((u32)lane, tag, w.b);
-        u32 cnt = w.cnt;
-        ploc_rounds_lds<true, false>(have, w.final_, cnt, tag, w.b, (u32)hbase, 32u, (u32)hbase, (u32)hbase + 31u, wl, nodes, zero_parent, lane, slot, hbase, nn);
-        w.cnt = cnt; w.id = wl.id(tag); w.rep = wl.rep(tag);
-    }
 #else
     ploc_rounds(w, nodes, zero_parent, ni, lane, slot, hbase, nn);
 #endif
@@ -1342,12 +1034,7 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     // storeIndices (:208-218): the <= 16 survivors of a non-root range, INVALID-terminated — unless they stay in registers
     const bool left_child = __shfl((int)(q == R), hbase) != 0;        // (the owner's q and R: this range is its parent's left child)
     if (have && !w.final_ && !hfast && slot < 16) node_store_agent(recs + rec_base(left_child, tL, tR) + slot, w.id, w.rep, w.b);
-#ifdef ABL_EXT_NOCLIMB   // in-situ probe: every queue item runs its first task only (how much of k_hploc_ext is throughput, how much the climb?)
-    if (owner) { ready = false; cw.side = 0; }
-    if (owner && false) {
-#else
     if (owner) {
-#endif
         ready = false; cw.side = 0;
         if (q != INV) {
             if (fast) { cw.side = (q == R) ? 1 : 2; L = nL; R = nR; ready = true; }
@@ -1357,13 +1044,9 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     }
     cw.id = w.id; cw.rep = w.rep; cw.b = w.b;
 #ifdef ABL_EXT_TRACE
-#if !defined(EXT_TRACE_NOHOOK)
     asm volatile("" : "+v"(L), "+v"(R));
     const u64 tr3 = __builtin_amdgcn_s_memrealtime();
     if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds, tr1, tr2, tr3);
-#else
-    if (have && slot == 0) ext_trace(trace, trace_count, trace_cap, tr0, trL, trR, ni, fast ? 1u : ready ? 2u : 3u, tr_rounds);
-#endif
 #endif
 #ifdef ABL_EXT_TIMING
     {   const u64 t3 = __builtin_amdgcn_s_memrealtime();
@@ -1400,14 +1083,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
                                                    const u32* __restrict__ q_pc, const u64* __restrict__ q_rng, u32* q_count, u32 q_cap, u32 n) {
     __shared__ u64 s_nn[256 / WAVE][WAVE];
     const int lane = tid_x() & (WAVE - 1);
-#if HPX_LDS_LIST          // (A/B switch, off: the per-wave work lists of that variant — 8 KB of LDS the default kernel does not reserve)
-    __shared__ u64 s_lir[256 / WAVE][WAVE];
-    __shared__ float2 s_lb[3][256 / WAVE][WAVE + 1];
-    const int wv = tid_x() / WAVE;
-    const WaveList wl{ s_lir[wv], s_lb[0][wv], s_lb[1][wv], s_lb[2][wv] };
-#else
     const WaveList wl{ nullptr, nullptr, nullptr, nullptr };
-#endif
     const u32 nwaves = nbid_x() * (256 / WAVE);
     const u32 wid = bid_x() * (256 / WAVE) + (u32)__builtin_amdgcn_readfirstlane((int)(tid_x() >> 6));   // (wave-uniform: the sub-queue's index, base and length live in SGPRs —
     const u32 sub = wid % HPQ_SUB;                                       //  as vector values two of them were spilled to scratch at 80 VGPRs; nwaves is a multiple of HPQ_SUB)
@@ -1416,9 +1092,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
     u64* const trace = const_cast<u64*>(q_rng) + (size_t)q_cap * (HPQ_SUB - 1) + q_cap / 2u;      // the unused second half of the last sub-queue's storage
     u32* const trace_count = q_count + 32u + 2u;                         // word 2 of sub-queue 1's padded head
     const u32 trace_cap = (q_cap / 2u) / 4u;
-#ifndef EXT_TRACE_NOSTART
     if (wid == 0u && lane == 0) { const u32 at = atomicAdd(trace_count, 1u); u64* e = trace + (size_t)at * 4u; e[0] = e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = 0ull; e[3] = 0ull; }   // kernel start
-#endif
 #endif
 #ifdef ABL_EXT_TIMING
     u32 profw[16] = { 0 };
@@ -1506,9 +1180,6 @@ size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SU
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                         void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared) {
     if (!heads_cleared) (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
-#ifdef ABL_EXT_STOP_ABOVE
-    (void)hipMemsetAsync(sc.dep, 0, (size_t)n * sizeof(u64), s);     // (the probe leaves the dependency words of the unprocessed top nodes dirty)
-#endif
     int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
     const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);

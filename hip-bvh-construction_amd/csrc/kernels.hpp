@@ -131,24 +131,17 @@ struct PlocScratch {
     uint32_t* ids1;          // u32[n]
     uint64_t* status;        // u64[PLOC_MAX_ITERS * chunks]
     uint32_t* state;         // u32[PLOC_STATE_WORDS]
-    void*     xchg = nullptr; // ploc_xchg_bytes(): the resident launch's exchange records (zeroed once; epochs only ever grow)
 };
 constexpr int PLOC_CHUNK = 1024;
 constexpr int PLOC_MAX_ITERS = 96;
-constexpr int PLOC_STATE_WORDS = 2 * PLOC_MAX_ITERS + 4;     // counts[MAX+1] | tickets[MAX] | iterations done | iterations of the resident launch
-constexpr int PLOC_RESIDENT_MAX_WG = 256;                    // workgroups (= 1024-cluster chunks) of the resident launch: one per CU
+constexpr int PLOC_STATE_WORDS = 2 * PLOC_MAX_ITERS + 4;     // counts[MAX+1] | tickets[MAX] | iterations done | (spare)
 inline uint32_t ploc_chunks(uint32_t n) { return (n + PLOC_CHUNK - 1) / PLOC_CHUNK; }
 void ploc_begin(hipStream_t s, const PlocScratch& sc, uint32_t n);
 void ploc_begin_prep(const PlocScratch& sc, uint32_t n, PrepArgs& prep);   // the same clearing as fields of the build path's first kernel (no launch)
 void ploc_reset(hipStream_t s, const PlocScratch& sc, uint32_t n, uint32_t count);
 // fresh: iteration `first` is the build's very first one — it reads d_svals / d_boxes and writes d_leaves (SetupClusters fused)
-size_t ploc_xchg_bytes();
-// the first iterations in ONE cooperative launch with the list resident in LDS (lists of 4..PLOC_RESIDENT_MAX_WG chunks); false: not applicable / not launchable,
-// use the per-iteration path from iteration 0.  On success the bookkeeping stands as after iteration 0: list in sc.list1, count in counts[1]; iterations done is
-// advanced by as many iterations as the launch ran (state word 2 * PLOC_MAX_ITERS + 2 holds that number)
-bool ploc_resident(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals, uint32_t epoch_base);
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals,
-                  int first, int count, int parity, bool fresh, int skipped = 0 /* iterations a resident launch ran before iteration `first` (launch shapes only) */);
+                  int first, int count, int parity, bool fresh);
 
 // ---- BVH2 -> BVH4 collapse (collapse.hip)
 constexpr int COLLAPSE_MAX_BATCH = 64;                       // levels per batch of launches (one counter word per level)

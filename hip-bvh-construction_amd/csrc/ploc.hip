@@ -19,26 +19,11 @@ namespace bvh {
 #ifndef PLOC_NARROW
 #define PLOC_NARROW 512
 #endif
-#ifndef PLOC_DEFER
-#define PLOC_DEFER 1     // 0: walk and store right away (measured at 10 M: emit 2.42 ms instead of 2.00, 2 M: 0.79 instead of 0.75)
-#endif
 #ifndef PLOC_NN_OWN_F64
 #define PLOC_NN_OWN_F64 1   // 1 (round 4): nn_pairs keeps an entry's own candidates in registers (v_min_f64 on the 64-bit key) and sends one atomic per entry; 0: both ends of every pair by LDS atomics
 #endif
-#ifndef PLOC_LATE
-#define PLOC_LATE 0          // A/B switch (off): 1 = the iterations of a list of at most PLOC_LATE_WG chunks run in ONE launch (k_ploc_late: a barrier between iterations instead of a
-                             //    launch boundary).  Same trees; measured slower — Sponza-like 262 144 0.3735 -> 0.3941 ms, 50 000 0.2366 -> 0.2516, 2 M / 10 M unchanged: an iteration
-                             //    inside the launch is a chain of ~7 coherent round trips (barrier poll, count, span, look-back, drain, arrival) at 1-1.6 us each; the launch boundary
-                             //    it replaces (5.4 us for a launch that finds nothing to do) is cheaper (LEADS.md row 75)
-#endif
-#ifndef PLOC_LATE_WG
-#define PLOC_LATE_WG 16
-#endif
 #ifndef PLOC_TAIL_PAIRS
 #define PLOC_TAIL_PAIRS 1
-#endif
-#ifndef PLOC_ONE_SHOT
-#define PLOC_ONE_SHOT 1
 #endif
 #ifndef PLOC_ONE_SHOT_MAX_N
 #define PLOC_ONE_SHOT_MAX_N (1 << 20)
@@ -79,22 +64,6 @@ __device__ __forceinline__ void entry_load(const float4* __restrict__ list, size
 __device__ __forceinline__ void entry_store(float4* __restrict__ list, size_t g, u32 id, const Box& b) {
     list[2 * g] = make_float4(__uint_as_float(id), b.lx, b.ly, b.lz);
     list[2 * g + 1] = make_float4(b.hx, b.hy, b.hz, 0.0f);
-}
-
-// the same entry written / read by different workgroups of ONE launch (k_ploc_late): 8-byte agent-scope accesses (sc1: the XCDs' L2s are not coherent with each other);
-// the writer drains its stores before it arrives at the launch's barrier
-template <bool AGENT>
-__device__ __forceinline__ void entry_load_t(const float4* __restrict__ list, size_t g, u32& id, Box& b) {
-    if (!AGENT) { entry_load(list, g, id, b); return; }
-    const u64* q = reinterpret_cast<const u64*>(list + 2 * g);
-    const u64 w0 = ld_agent(q), w1 = ld_agent(q + 1), w2 = ld_agent(q + 2), w3 = ld_agent(q + 3);
-    id = (u32)w0; b = { hi_f(w0), lo_f(w1), hi_f(w1), lo_f(w2), hi_f(w2), lo_f(w3) };
-}
-template <bool AGENT>
-__device__ __forceinline__ void entry_store_t(float4* __restrict__ list, size_t g, u32 id, const Box& b) {
-    if (!AGENT) { entry_store(list, g, id, b); return; }
-    u64* q = reinterpret_cast<u64*>(list + 2 * g);
-    st_agent(q, (u64)id | ((u64)__float_as_uint(b.lx) << 32)); st_agent(q + 1, pack2(b.ly, b.lz)); st_agent(q + 2, pack2(b.hx, b.hy)); st_agent(q + 3, pack2(b.hz, 0.0f));
 }
 
 // nearest neighbour of span entry k among valid entries [lo, hi) within +-8, key {area bits, position}
@@ -236,17 +205,14 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
 #define PLOC_OCC 5
 #endif
 // One iteration as workgroup `wg` of `G`.  Returns true when the build is over (one cluster left, or this workgroup has nothing more to do in it).
-// LATE (k_ploc_late: several iterations in one launch, a barrier between them): chunks are dealt statically (wg, wg + G, ...: all G workgroups are resident), list
-// entries and counts go through agent-scope accesses (they cross workgroups INSIDE the launch), and a final count is written to every counts[1 .. n_fwd] (the
-// per-iteration launches pass it on one launch at a time: the host reads the batch's last word).
-template <int PL_BLOCK, bool FIRST, bool LATE>
+template <int PL_BLOCK, bool FIRST>
 __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restrict__ list_in, float4* __restrict__ list_out, bvh2_node* __restrict__ nodes,
                                                u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
                                                const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
-                                               const u32 wg, const u32 G, const u32 n_fwd) {
+                                               const u32 wg, const u32 G) {
     constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
-    const u32 C = LATE ? ld_agent(counts) : counts[0];
-    auto set_count = [&](u32 v) { if (LATE) { for (u32 j = 1; j <= n_fwd; ++j) st_agent(counts + j, v); } else counts[1] = v; };
+    const u32 C = counts[0];
+    auto set_count = [&](u32 v) { counts[1] = v; };
     if (C <= 1) { if (wg == 0 && tid_x() == 0) set_count(C); return true; }
     const int tid = tid_x();
     // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
@@ -259,7 +225,7 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
                 reinterpret_cast<u32*>(f)[0] = prim;
                 f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
             }
-        } else entry_load_t<LATE>(list_in, g, id, b);
+        } else entry_load(list_in, g, id, b);
     };
 
     auto nn_pairs = [&](const int lo, const int hi) { nn_pairs_fn<PL_BLOCK>(s, tid, lo, hi); };
@@ -357,7 +323,7 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
                 s.bcast[1] = (u32)(excl >> 31); s.bcast[2] = (u32)(excl & 0x7FFFFFFFull);
                 if (chunk == chunks - 1) {                                                                                   // src/PLOC++Bvh.cpp:150
                     const u32 left = C - ((u32)(excl >> 31) + (tot >> 16));
-                    if (LATE) st_agent(counts + 1, left); else counts[1] = left;
+                    counts[1] = left;
                     atomicAdd(iters_done, 1u);
                 }
             }
@@ -372,18 +338,16 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
                     id = C - 2 - (m_ex + (ex >> 16));                                                // :311
                     node_store_plain(nodes + id, cid[q], pid[q], cb[q]);
                 }
-                if (PLOC_ABL != 3) entry_store_t<LATE>(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);           // :355-361
+                if (PLOC_ABL != 3) entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb[q]);           // :355-361
             }
             ex += ((u32)mrg[q] << 16) + (u32)keep[q];
         }
     };
     for (u32 trip = 0; ; ++trip) {
         __syncthreads();
-        if (!LATE) {
-            if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
-            __syncthreads();
-        }
-        const u32 chunk = LATE ? wg + trip * G : s.bcast[0];
+        if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
+        __syncthreads();
+        const u32 chunk = s.bcast[0];
         if (chunk >= chunks) break;
         const long long o = (long long)chunk * PLOC_CHUNK;
         // span entry k <-> list position o - HALO + k   (:232-249)
@@ -398,7 +362,7 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
                 const long long gpos = o - PL_HALO + k;
                 in_[q] = k < PL_SPAN && gpos >= 0 && gpos < (long long)C;
                 const size_t gc = in_[q] ? (size_t)gpos : (size_t)o;                 // (o < C: the chunk exists)
-                if (FIRST) prim_[q] = svals[gc]; else entry_load_t<LATE>(list_in, gc, id_[q], b_[q]);
+                if (FIRST) prim_[q] = svals[gc]; else entry_load(list_in, gc, id_[q], b_[q]);
             }
             if (FIRST) {
 #pragma unroll
@@ -448,25 +412,17 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
             const u64 mine = ((u64)(tot >> 16) << 31) | (u64)(tot & 0xFFFFu);
             __hip_atomic_store(status + chunk, ((chunk == 0 || PLOC_ABL == 1) ? PS_INCL : PS_LOCAL) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#if PLOC_DEFER
         if (p_have) { __syncthreads(); finish(p_chunk, p_tot, p_ex, p_cid, p_pid, p_cb, p_mrg, p_keep); }
         p_have = true; p_chunk = chunk; p_tot = tot; p_ex = ex;
 #pragma unroll
         for (int q = 0; q < PL_CPT; ++q) { p_cid[q] = cid[q]; p_pid[q] = pid[q]; p_cb[q] = cb[q]; p_mrg[q] = mrg[q]; p_keep[q] = keep[q]; }
-#else
-        finish(chunk, tot, ex, cid, pid, cb, mrg, keep);
-#endif
-#if PLOC_ONE_SHOT
         // the grid covers the iteration's chunks (every late iteration): when no workgroup takes a second ticket the first `chunks` tickets go to
         // `chunks` different workgroups, so nobody needs to ask again just to learn that the list is used up — the finish below starts a round trip earlier
         // Measured on the MI355X (whole build, same box): Sponza-like 262 144 0.4107 -> 0.4065 ms, 524 288 0.5216 -> 0.5180, uniform 1 M 0.5630 -> 0.5605; but 2 M
         // 0.783 -> 0.790 and 10 M 2.206 -> 2.245 (there the second ticket's round trip is what gives the predecessors time to publish before the walk): small inputs only
-        if (!LATE && G >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;            // (grid-uniform)
-#endif
+        if (G >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;            // (grid-uniform)
     }
-#if PLOC_DEFER
     if (p_have) { __syncthreads(); finish(p_chunk, p_tot, p_ex, p_cid, p_pid, p_cb, p_mrg, p_keep); }
-#endif
     return false;
 }
 
@@ -476,185 +432,7 @@ __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_
                                                         u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
                                                         const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
     __shared__ PlocLds s;
-    (void)ploc_iter_body<PL_BLOCK, FIRST, false>(s, list_in, list_out, nodes, status, counts, tickets, iters_done, ni, boxes, svals, leaves, bid_x(), nbid_x(), 1u);
-}
-
-// The late iterations in ONE launch (round 4).  Traced at Sponza-like 262 144 (tools/prof_ploc.sh): an iteration launch that finds nothing to do takes 5.4 us from
-// start to end, the iterations of the last <= 16 chunks 7.2-7.7 us each — two thirds of a late iteration is the launch boundary.  Here PLOC_LATE_WG workgroups run
-// iterations k_begin .. k_end - 1 back to back: static chunks (workgroup w takes w, w + G, ...), the usual look-back inside an iteration, and between two iterations
-// a barrier on the iteration's (otherwise unused) ticket word: every wave drains its write-through list stores, one thread arrives and polls until all G have.  The
-// list entries and the counts cross workgroups inside the launch: agent-scope accesses (ploc_iter_body<LATE>).  G is small (16 x 1024 threads of a device that holds
-// 512 such workgroups), so the launch's workgroups are resident together whenever the stream has the device's attention; were some of them delayed by other streams'
-// kernels, the others wait at the barrier / in the look-back until those kernels end — nothing here waits for a workgroup that can never start.
-// Same result as the per-iteration launches: the chunking does not enter the result (the look-back's prefix sums are those of the list order), and it never did —
-// the ticket order of k_ploc_iter is not deterministic either.
-template <int PL_BLOCK>
-__global__ __launch_bounds__(PL_BLOCK, 4) void k_ploc_late(float4* list0, float4* list1, bvh2_node* __restrict__ nodes, u64* status_base, u32 chunks_n,
-                                                           u32* counts_base, u32* tickets_base, u32* iters_done, u32 ni, u32 k_begin, u32 k_end, u32 parity) {
-    __shared__ PlocLds s;
-    const u32 G = nbid_x(), wg = bid_x();
-    for (u32 k = k_begin; k < k_end; ++k) {
-        const bool even = ((k + parity) & 1u) == 0u;
-        const float4* in = even ? list0 : list1; float4* out = even ? list1 : list0;
-        if (ploc_iter_body<PL_BLOCK, false, true>(s, in, out, nodes, status_base + (size_t)k * chunks_n, counts_base + k, tickets_base + k, iters_done, ni,
-                                                  nullptr, nullptr, nullptr, wg, G, k_end - k)) return;
-        if (k + 1 == k_end) return;
-        drain_stores();                                  // this wave's list entries (and the next count) are in memory ...
-        __syncthreads();                                 // ... and so are the other waves' ...
-        if (tid_x() == 0) {                              // ... before the workgroup arrives
-            __hip_atomic_fetch_add(tickets_base + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (ld_agent(tickets_base + k) < G) __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
-    }
-}
-
-// =====================================================================================================================
-// Resident iterations (round 4): for lists of at most PLOC_RESIDENT_MAX_WG chunks — config 4's Sponza-class 262 144 is exactly 256 — ONE
-// cooperative launch of one 1024-thread workgroup per chunk runs the first iterations with every workgroup's part of the list RESIDENT IN LDS.  A launch-per-
-// iteration pass re-reads its 32-byte entries through L2, walks a look-back chain and writes the compacted list back, every time (~11 us per iteration at 262 144,
-// of which the work is ~3); here an iteration is: nearest neighbours on the LDS span, merge decisions, block scan, ONE global exchange, node stores, compaction in LDS.
-// The exchange: a workgroup publishes {epoch, merges, kept} in one 64-bit word and the first / last 16 entries of its NEW list part (the halos its neighbours need for
-// the next iteration; a cluster merged in this very iteration is published as its local merge rank — the reader resolves the node index from the prefix it computes
-// anyway), then reads everybody's word: prefix of the merges before it (node index = C - 2 - rank in list order: the same deterministic numbering as k_ploc_iter), the new
-// cluster count, the smallest part.  Parts shrink ~20 % per iteration and are NOT rebalanced: the launch ends when the smallest part falls below the halo width (16)
-// or the list below two chunks, writes the list out in order and the ordinary per-iteration launches finish the build (~10 of ~30 iterations at 262 144).
-// Co-residency is guaranteed by the cooperative launch (which fails — and the host falls back to the per-iteration path — when the device cannot hold the grid).
-// The chunking itself does not matter for the result: with a halo of 2 x radius every cluster sees the same 16 neighbours whatever the partition (:232-270).
-// =====================================================================================================================
-struct PlocXchg {                          // one per workgroup and parity
-    u64 word;                              // {epoch : 32 | merges : 16 | kept : 16}
-    u64 pad;
-    float4 first[PL_HALO][2];              // entries {idcode, lx, ly, lz} {hx, hy, hz, -}; idcode: node / leaf id, or 0x80000000 | local merge rank of this iteration
-    float4 last[PL_HALO][2];
-};
-static_assert(sizeof(PlocXchg) == 16 + 2 * PL_HALO * 32, "exchange record");
-size_t ploc_xchg_bytes() { return 2 * (size_t)PLOC_RESIDENT_MAX_WG * sizeof(PlocXchg); }
-
-__device__ __forceinline__ void xchg_store(float4* e, u32 code, const Box& b) {          // two 16-byte write-through stores (drained before the epoch moves)
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f q0 = { __uint_as_float(code), b.lx, b.ly, b.lz }, q1 = { b.hx, b.hy, b.hz, 0.0f };
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1" :: "v"(e), "v"(q0), "v"(q1) : "memory");
-}
-__device__ __forceinline__ void xchg_load(const float4* e, u32& code, Box& b) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f q0, q1;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(e) : "memory");
-    code = __float_as_uint(q0.x); b = { q0.y, q0.z, q0.w, q1.x, q1.y, q1.z };
-}
-
-__global__ __launch_bounds__(PLOC_CHUNK, 1) void k_ploc_resident(PlocXchg* xchg, u32 epoch_base, float4* __restrict__ list_out, bvh2_node* __restrict__ nodes,
-                                                                u32* counts, u32* iters_done, u32* resident_iters, u32 n, u32 max_iters,
-                                                                const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
-    __shared__ PlocLds s;
-    __shared__ u32 s_red[8];               // [0] merges before this part, [1] all merges, [2] kept before, [3] smallest part, [4] merges of the left neighbour
-    const int tid = tid_x();
-    const u32 w = bid_x(), G = nbid_x(), ni = n - 1u;
-    u32 C = n;
-    u32 m = n - w * (u32)PLOC_CHUNK < (u32)PLOC_CHUNK ? n - w * (u32)PLOC_CHUNK : (u32)PLOC_CHUNK;       // this part: span entries [HALO, HALO + m)
-    // the first list is the sorted leaves themselves (SetupClusters :39-55 fused): part + halos straight from the boxes
-    for (int k = tid; k < PL_SPAN; k += PLOC_CHUNK) {
-        const long long g = (long long)w * PLOC_CHUNK - PL_HALO + k;
-        if (g >= 0 && g < (long long)n && k < PL_HALO + (int)m + PL_HALO) {
-            const u32 prim = svals[g];
-            const Box b = box_gather(boxes + prim);
-            if (k >= PL_HALO && k < PL_HALO + (int)m) {
-                float* f = reinterpret_cast<float*>(leaves + g);
-                reinterpret_cast<u32*>(f)[0] = prim;
-                f[1] = b.lx; f[2] = b.ly; f[3] = b.lz; f[4] = b.hx; f[5] = b.hy; f[6] = b.hz;
-            }
-            lds_set(s, k, (u32)g + ni, b);
-        } else s.id[k] = INV;
-        s.nn[k] = ~0ull;
-    }
-    __syncthreads();
-    u32 it = 0;
-    while (true) {
-        const int lo = w > 0u ? 0 : PL_HALO;
-        const int hi = PL_HALO + (int)m + (w + 1u < G ? PL_HALO : 0);
-        nn_pairs_fn<PLOC_CHUNK>(s, tid, lo, hi);
-        __syncthreads();
-        // merge decisions of this part's clusters (:274-320), one per thread
-        const int k = PL_HALO + tid;
-        bool mrg = false, keep = false; u32 cid = INV, pid = INV; Box cb = box_empty();
-        if (tid < (int)m) {
-            const u32 nb = (u32)s.nn[k];
-            const bool mutual = (u32)s.nn[nb] == (u32)k;
-            mrg = mutual && (u32)k < nb; keep = !mutual || mrg;
-            cid = s.id[k]; cb = lds_box(s, k);
-            if (mrg) { pid = s.id[nb]; cb = box_union(cb, lds_box(s, (int)nb)); }
-        }
-        u32 tot; const u32 ex = block_scan<PLOC_CHUNK>(s, ((u32)mrg << 16) + (u32)keep, &tot);
-        const u32 my_merges = tot >> 16, my_kept = tot & 0xFFFFu;
-        // ---- publish: the halos of the NEW list part, then {epoch, merges, kept}
-        PlocXchg* const X = xchg + (size_t)(it & 1u) * PLOC_RESIDENT_MAX_WG;
-        if (keep) {
-            const u32 p = ex & 0xFFFFu;
-            const u32 code = mrg ? (0x80000000u | (ex >> 16)) : cid;
-            if (p < (u32)PL_HALO) xchg_store(&X[w].first[p][0], code, cb);
-            if (p + (u32)PL_HALO >= my_kept) xchg_store(&X[w].last[p + (u32)PL_HALO - my_kept][0], code, cb);
-        }
-        if (tid == 0) { s_red[0] = 0u; s_red[1] = 0u; s_red[2] = 0u; s_red[3] = 0xFFFFFFFFu; s_red[4] = 0u; }
-        drain_stores();
-        __syncthreads();                                       // every thread's entry stores are in memory
-        const u32 target = epoch_base + it + 1u;
-        if (tid == 0) st_agent(&X[w].word, ((u64)target << 32) | ((u64)my_merges << 16) | (u64)my_kept);
-        // ---- everybody's word: prefix of the merges / kept before this part, the new count, the smallest part
-        if ((u32)tid < G) {
-            u64 v;
-            while (true) { v = ld_agent(&X[tid].word); if ((u32)(v >> 32) == target) break; __builtin_amdgcn_s_sleep(1); }
-            const u32 mg = (u32)(v >> 16) & 0xFFFFu, kp = (u32)v & 0xFFFFu;
-            if ((u32)tid < w) { atomicAdd(&s_red[0], mg); atomicAdd(&s_red[2], kp); }
-            if ((u32)tid + 1u == w) s_red[4] = mg;
-            atomicAdd(&s_red[1], mg); atomicMin(&s_red[3], kp);
-        }
-        __syncthreads();
-        const u32 m_ex = s_red[0], all_merges = s_red[1], k_ex = s_red[2], min_kept = s_red[3], left_merges = s_red[4];
-        u32 id = cid;
-        if (keep && mrg) { id = C - 2u - (m_ex + (ex >> 16)); node_store_plain(nodes + id, cid, pid, cb); }      // :311
-        const u32 Cn = C - all_merges;
-        ++it;
-        if (min_kept < (u32)PL_HALO || Cn < 2u * (u32)PLOC_CHUNK || it >= max_iters) {
-            // ---- hand the list to the per-iteration launches: in order, as iteration `1` of the bookkeeping expects it
-            if (keep) entry_store(list_out, (size_t)(k_ex + (ex & 0xFFFFu)), id, cb);
-            if (w == 0u && tid == 0) { counts[1] = Cn; atomicAdd(iters_done, it); *resident_iters = it; }
-            return;
-        }
-        // ---- the new part in LDS (every read of the old one is done: block_scan's barriers and the one above), its halos from the neighbours' publication
-        if (keep) lds_set(s, PL_HALO + (int)(ex & 0xFFFFu), id, cb);
-        m = my_kept;
-        __syncthreads();
-        if (tid < 2 * PL_HALO) {
-            const bool left = tid < PL_HALO;
-            const int e = left ? tid : tid - PL_HALO;
-            const int at = left ? e : PL_HALO + (int)m + e;
-            if (left ? w > 0u : w + 1u < G) {
-                u32 code; Box b;
-                xchg_load(left ? &X[w - 1u].last[e][0] : &X[w + 1u].first[e][0], code, b);
-                if (code & 0x80000000u) code = C - 2u - ((left ? m_ex - left_merges : m_ex + my_merges) + (code & 0x7FFFFFFFu));      // a cluster the neighbour merged in this iteration
-                lds_set(s, at, code, b);
-            } else s.id[at] = INV;
-        }
-        for (int q = tid; q < PL_SPAN; q += PLOC_CHUNK) s.nn[q] = ~0ull;
-        C = Cn;
-        __syncthreads();
-    }
-}
-
-// true: the resident launch was enqueued (it leaves the list in sc.list1 and the count in counts[1], like iteration 0 of the per-iteration path)
-bool ploc_resident(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals, uint32_t epoch_base) {
-    const u32 chunks = ploc_chunks(n);
-    const u32 last = n - (chunks - 1u) * (u32)PLOC_CHUNK;
-    if (chunks < 4u || chunks > (u32)PLOC_RESIDENT_MAX_WG || last < (u32)PL_HALO || !sc.xchg) return false;
-    PlocXchg* xchg = (PlocXchg*)sc.xchg; float4* list_out = (float4*)sc.list1; bvh2_node* nodes = (bvh2_node*)d_nodes;
-    u32* counts = sc.state; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1; u32* res = sc.state + 2 * PLOC_MAX_ITERS + 2;
-    u32 nn = n, max_iters = (u32)PLOC_MAX_ITERS - 8u, eb = epoch_base;
-    const bvh_aabb* boxes = (const bvh_aabb*)d_boxes; const u32* svals = d_svals; bvh_primref* leaves = (bvh_primref*)d_leaves;
-    void* args[] = { &xchg, &eb, &list_out, &nodes, &counts, &done, &res, &nn, &max_iters, &boxes, &svals, &leaves };
-    KernelScope ks(s, "k_ploc_resident");
-    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_ploc_resident), dim3(chunks), dim3(PLOC_CHUNK), args, 0, s);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    return true;
+    (void)ploc_iter_body<PL_BLOCK, FIRST>(s, list_in, list_out, nodes, status, counts, tickets, iters_done, ni, boxes, svals, leaves, bid_x(), nbid_x());
 }
 
 // one launch clears the per-iteration bookkeeping (two memsets + a one-thread kernel before: three launch boundaries of ~2 us in front of every build)
@@ -686,24 +464,17 @@ void ploc_begin_prep(const PlocScratch& sc, uint32_t n, PrepArgs& prep) {
 // is correct because chunks are taken from a ticket counter, a good guess is merely faster.
 // fresh: iteration `first` is the build's very first one (reads svals / boxes, writes the leaves: fused SetupClusters)
 void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_nodes, void* d_leaves, const void* d_boxes, const uint32_t* d_svals,
-                  int first, int count, int parity, bool fresh, int skipped) {
+                  int first, int count, int parity, bool fresh) {
     const u32 chunks = ploc_chunks(n);
     u32* counts = sc.state; u32* tickets = sc.state + PLOC_MAX_ITERS + 1; u32* done = sc.state + 2 * PLOC_MAX_ITERS + 1;
     KernelScope ks(s, "k_ploc_iter");                   // the batch of launches is timed as one group
     for (int k = first; k < first + count; ++k) {
         const bool even = ((k + parity) & 1) == 0;
-        double guess = (double)chunks; for (int j = 0; j < k + skipped; ++j) guess *= 0.83;      // chunks expected at iteration k, generously (skipped: iterations a resident launch ran as "iteration 0")
+        double guess = (double)chunks; for (int j = 0; j < k; ++j) guess *= 0.83;      // chunks expected at iteration k, generously
         const bool wide = guess <= 1024.0;                                              // a few workgroups per CU at most: latency matters
         u32 grid = (u32)(2.0 * guess) + 8u; if (grid > (wide ? 512u : 1024u)) grid = wide ? 512u : 1024u; if (grid > chunks) grid = chunks;
         const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);
         const bool f0 = fresh && k == first;
-#if PLOC_LATE
-        if (!f0 && guess <= (double)PLOC_LATE_WG) {      // the rest of the batch in one launch (the guess is generous: the list has at most that many chunks)
-            hipLaunchKernelGGL((k_ploc_late<1024>), dim3(PLOC_LATE_WG < chunks ? PLOC_LATE_WG : chunks), dim3(1024), 0, s, (float4*)sc.list0, (float4*)sc.list1, (bvh2_node*)d_nodes,
-                               sc.status, chunks, counts, tickets, done, n - 1, (u32)k, (u32)(first + count), (u32)parity);
-            break;
-        }
-#endif
 #define PLOC_LAUNCH(BLK, FIRST) hipLaunchKernelGGL((k_ploc_iter<BLK, FIRST>), dim3(grid), dim3(BLK), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, \
                                                    counts + k, tickets + k, done, n - 1, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves)
         if (wide) { if (f0) PLOC_LAUNCH(1024, true); else PLOC_LAUNCH(1024, false); }

@@ -30,16 +30,8 @@ static_assert(SORT_BLOCK == SORT_RADIX, "one thread per digit (k_onesweep: the f
 constexpr u32 ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 
 // interleaved {key, value} records of the intermediate passes: 8 bytes for u32 keys, 16 bytes {key, value, pad} for u64 keys
-// A/B switch (off): non-temporal key / value traffic of the passes (SORT_NT bit 0: tile loads, bit 1: scattered stores) — an attempt to keep the 240 MB
-// of primitive boxes in the 256 MiB Infinity Cache across the sort for the emitters' random gather.  Measured: see DESIGN.md section 9.
-#ifndef SORT_NT
-#define SORT_NT 0
-#endif
-#ifndef SORT_PRIO
-#define SORT_PRIO 0
-#endif
-template <typename T> __device__ __forceinline__ T sort_ld(const T* p) { if constexpr ((SORT_NT & 1) && sizeof(T) <= 8) return __builtin_nontemporal_load(p); else return *p; }
-template <typename T> __device__ __forceinline__ void sort_st(T* p, T v) { if constexpr ((SORT_NT & 2) && sizeof(T) <= 8) __builtin_nontemporal_store(v, p); else *p = v; }
+template <typename T> __device__ __forceinline__ T sort_ld(const T* p) { return *p; }
+template <typename T> __device__ __forceinline__ void sort_st(T* p, T v) { *p = v; }
 #define SORT_LD(P) sort_ld(P)
 #define SORT_ST(P, V) sort_st(P, V)
 template <typename K> struct PairRec;
@@ -100,12 +92,6 @@ static_assert(SORT_NARROW_NT * SORT_NARROW_IPT == SORT_TILE, "the status rows ar
 #endif
 template <typename K> struct SortWide { static constexpr int NT = 512, IPT = SORT_WIDE_IPT; };
 template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };    // 5120-pair tiles, 68 KB: 8 passes at 10 M 0.656 (256 x 20) -> 0.610 ms; 512 x 8: 0.657, 512 x 12: 0.731
-#ifndef SORT_EARLY_PUBLISH
-#define SORT_EARLY_PUBLISH 0     // 1: the totals go out before the ranking (A/B switch; measured slower, see the comment at its use)
-#endif
-#ifndef SORT_EXCHANGE_FIRST
-#define SORT_EXCHANGE_FIRST 1
-#endif
 // BITS: digit width of this instantiation's pass (6..8; a pass whose digit is narrower than BITS passes a smaller digit_mask).  Status rows keep their
 // SORT_RADIX-word stride; a pass only touches the first 2^BITS words of a row.
 // GATE (SORT_WIDE_FLAG_WORD, kernels.hpp): 1 = the build's narrow top pass, which leaves at once when the Morton kernel saw a code beyond the bit range this
@@ -129,9 +115,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #ifdef BVH_ABLATION
     __shared__ u32 s_tile;                           // (ticket order of the measurement build)
 #endif
-#if SORT_EARLY_PUBLISH
-    __shared__ u32 s_cnt[RADIX];
-#endif
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
 #ifdef BVH_ABLATION
@@ -144,9 +127,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     u32 gate_word = 0u;
     if (GATE == 1) gate_word = ghist[SORT_RADIX];                 // a scalar load that travels with the tile's key loads; tested behind them
     SORT_STAMP();                                    // 0: start
-#if SORT_PRIO
-    __builtin_amdgcn_s_setprio(3);                   // A/B switch (off): a tile runs at high priority until its digit totals are published (its successors wait for them)
-#endif
     // Tile id = workgroup id.  Decoupled look-back makes a tile wait for its predecessors' totals; with static ids that is only deadlock-free
     // if every predecessor is (or gets) resident, which HIP's dispatch order does not promise.  The usual cure — tile ids from an atomic
     // ticket — costs a returning atomic on ONE word per tile (~90 per us on this chip): the ~1000 workgroups that start together queued up to
@@ -162,10 +142,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     // every wave clears ITS row of the per-wave digit counters (the ranking only touches the wave's own row, and a wave's LDS operations execute in order): no barrier
     // between the clearing and the ranking, and the tile's key loads go out at once (round 4: the tile id used to come through LDS behind a barrier)
     for (int d = lane; d < RADIX; d += WAVE) s_whist[wave][d] = 0;
-#if SORT_EARLY_PUBLISH
-    if (dig) s_cnt[tid] = 0;
-    __syncthreads();
-#endif
 #ifdef BVH_ABLATION
     __syncthreads();
     const u32 tile = s_tile;
@@ -194,19 +170,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     if (dbg & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     SORT_STAMP();                                    // 1: ticket + loads landed
-#if SORT_EARLY_PUBLISH
-    // ---- A/B switch (off): the tile's digit totals go out BEFORE the ranking (a plain LDS-atomic count).  Measured on the MI355X, 10 M keys, round 3:
-    // empty polls per tile 7.3 -> 5.7 and the look-back 32 k -> 28 k of a tile's 68 k ticks, but four passes 0.244 -> 0.252 ms (2 M: 0.0949 -> 0.0956).  What a
-    // tile waits for is not its predecessors' ranking: with ticket order (BVH_SORT_DEBUG=64) the empty polls vanish (0.8 per tile) and a look-back is
-    // still 5.4 steps of ~1.6 us — the loaded latency of a coherent (sc1) status load — while the ticket itself costs more than it saves (0.265 ms).
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const u32 local = (u32)(wave * WAVE * IPT + i * WAVE + lane);
-        if (local < valid) atomicAdd(&s_cnt[(u32)(key[i] >> shift) & digit_mask], 1u);
-    }
-    __syncthreads();
-    if (dig) st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | s_cnt[tid]);
-#endif
     // ---- rank inside the wave: lanes holding the same digit form a group (8 ballots); every member reads the wave's LDS
     // counter for that digit, the group's lowest lane bumps it; rank = counter-before + index inside the group.  Program order
     // (item-major, then lane) is exactly memory order inside the wave's span => stable.
@@ -241,13 +204,8 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         for (int w = 0; w < NW; ++w) { const u32 c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
         total = run;
         if ((u32)tid == digit_mask) total -= (u32)TILE - valid;     // padding keys (all ones) carry the top digit; they are not data
-#if !SORT_EARLY_PUBLISH
         st_agent(&status[(size_t)tile * SORT_RADIX + tid], (tile == 0 ? ST_INCL : ST_LOCAL) | total);
-#endif
     }
-#if SORT_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     // ---- exclusive scans over the 256 digits (wave scan + LDS hop), two in one: the tile's digit totals -> s_binoff, and the pass's
     // raw global digit counts -> gexcl (every tile redoes that 256-entry scan from L2: cheaper than a kernel launch per sort)
     u32 gexcl = 0;
@@ -271,7 +229,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
             s_binoff[tid] = (u32)ex; gexcl = (u32)(ex >> 32);
         }
     }
-#if SORT_EXCHANGE_FIRST
     // ---- tile-local sort through LDS, ahead of the look-back: it needs nothing from other tiles, and the predecessors publish meanwhile
     __syncthreads();
 #pragma unroll
@@ -280,7 +237,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
         const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
         s_keys[p] = key[i]; s_vals[p] = val[i];
     }
-#endif
     SORT_STAMP();                                    // 3: totals published, scans, exchange writes
     // ---- decoupled look-back for digit `tid`: LB_WINDOW predecessors are fetched per step (independent loads in flight)
     // so that a walk over k tiles costs ~k/LB_WINDOW memory round trips instead of k.  Measured at 10 M (BVH_SORT_DEBUG=16 in the
@@ -345,16 +301,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
     __syncthreads();
     SORT_STAMP();                                    // 5: everybody's look-back done
 
-#if !SORT_EXCHANGE_FIRST
-    // ---- tile-local sort through LDS
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const u32 d = (u32)(key[i] >> shift) & digit_mask;
-        const u32 p = s_binoff[d] + s_whist[wave][d] + pos[i];
-        s_keys[p] = key[i]; s_vals[p] = val[i];
-    }
-    __syncthreads();
-#endif
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const u32 p = (u32)(k * NT + tid);

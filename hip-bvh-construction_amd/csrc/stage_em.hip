@@ -312,9 +312,6 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
 
 // HIST_BITS > 0: also accumulate the per-pass digit histograms of the LSD radix sort that follows (digits of HIST_BITS
 // bits starting at bit 0, `passes` of them) — LDS histogram per block, flushed with one global atomic per non-empty bin.
-#ifndef MORTON_REVERSE
-#define MORTON_REVERSE 1
-#endif
 template <int HIST_BITS>
 __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
                                                      u32* __restrict__ keys, u32* __restrict__ vals, u32 n,
@@ -322,13 +319,6 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
     if (reset_next && blockIdx.x == 0 && threadIdx.x < 6) reset_next[threadIdx.x] = threadIdx.x < 3 ? FMAX : -FMAX;     // Aabb::reset of the NEXT build's extent
     __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
     constexpr int RADIX = HIST_BITS > 0 ? (1 << HIST_BITS) : 1;
-#ifdef MORTON_P0_ROWS
-    // Cost probe (second half): what would it cost this kernel to ALSO leave the first sort pass's per-tile digit counts (one 256-word row per
-    // 6656-key sort tile, so that pass 0 needs no look-back)?  Every workgroup takes a contiguous run of 256-key tiles instead of a grid-strided one, counts digit 0
-    // per sort tile in LDS and flushes a row with one atomic per non-empty bin whenever its run crosses a sort-tile boundary.  Timing only: nothing consumes the rows.
-    __shared__ u32 s_row[256];
-    if (p0_rows) s_row[threadIdx.x] = 0;
-#endif
     __shared__ u32 s_hist[HIST_BITS > 0 ? 4 * RADIX : 1];
     __shared__ u32 s_pad[MORTON_GROUP >= 3 ? 64 : 1];
     if (threadIdx.x == 0) make_plan(scene, s_plan, s_lo, s_ext);
@@ -338,31 +328,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
     const float lo[3] = { s_lo[0], s_lo[1], s_lo[2] }, ext[3] = { s_ext[0], s_ext[1], s_ext[2] };
     // tiles in descending order: stage E wrote the boxes in ascending order just before, so the last ones are the ones still in the caches
     const u32 ntile = (n + EM_BLOCK - 1) / EM_BLOCK;
-#ifdef MORTON_P0_ROWS
-    const u32 per = (ntile + gridDim.x - 1) / gridDim.x;
-    const u32 t_begin = p0_rows ? blockIdx.x * per : blockIdx.x, t_end = p0_rows ? min(ntile, t_begin + per) : ntile, t_step = p0_rows ? 1u : gridDim.x;
-    u32 cur_row = 0xFFFFFFFFu;
-    for (u32 tile = t_begin; tile < t_end; tile += t_step) {
-        if (p0_rows) {
-            const u32 row = (ntile - 1u - tile) / ((512 * 13) / EM_BLOCK);      // (the wide sort tile: 512 threads x 13 keys)
-            if (row != cur_row) {                              // (uniform)
-                if (cur_row != 0xFFFFFFFFu) {
-                    __syncthreads();
-                    const u32 c = s_row[threadIdx.x]; if (c) atomicAdd(&p0_rows[(size_t)cur_row * 256 + threadIdx.x], c);
-                    s_row[threadIdx.x] = 0;
-                    __syncthreads();
-                }
-                cur_row = row;
-            }
-        }
-#else
     for (u32 tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-#endif
-#if MORTON_REVERSE
         const u32 i = (ntile - 1u - tile) * EM_BLOCK + threadIdx.x;
-#else
-        const u32 i = tile * EM_BLOCK + threadIdx.x;
-#endif
         if (i >= n) continue;
         const Box b = box_load(boxes + i);
         // centre = (max + min) * 0.5f (src/Common.h:347); p = (centre - scene.min) / extent with IEEE divides (:381)
@@ -372,17 +339,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
         if (vals) vals[i] = i;                                   // :384
         if (HIST_BITS > 0) {
             hist_add_passes<MORTON_GROUP>(s_hist, passes, RADIX, [&](int ps) { return (code >> (ps * HIST_BITS)) & (u32)(RADIX - 1); }, s_pad);
-#ifdef MORTON_P0_ROWS
-            if (p0_rows) atomicAdd(&s_row[code & 255u], 1u);
-#endif
         }
     }
-#ifdef MORTON_P0_ROWS
-    if (p0_rows && cur_row != 0xFFFFFFFFu) {
-        __syncthreads();
-        const u32 c = s_row[threadIdx.x]; if (c) atomicAdd(&p0_rows[(size_t)cur_row * 256 + threadIdx.x], c);
-    }
-#endif
     if (HIST_BITS > 0) {
         __syncthreads();
         u32* copy = hist + (blockIdx.x % SORT_HIST_COPIES) * SORT_HIST_STRIDE;      // (kernels.hpp: why there are several copies)

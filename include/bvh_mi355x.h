@@ -48,8 +48,8 @@ typedef enum {
     BVH_OPT_LBVH_SCHEDULER  = 1,   /* 0 auto (by n; default), 1 one-launch kernels (k_lbvh_single / k_karras + k_refit), 2 tile scheduler (k_lbvh_block / k_lbvh_ext) */
     BVH_OPT_SORT_TEST_KNOBS = 2,   /* bit mask, default 0; results are identical for every value.  8: tiles are handed out in reverse order; 32: threads help at
                                       the first empty poll (both force the one-sweep sort's helping path, which in-order dispatch never takes) */
-    BVH_OPT_PLOC_SCHEDULER  = 3    /* 0 auto (default: = 1), 1 one launch per iteration throughout (device-side loop, single-workgroup tail), 2 the first iterations in one
-                                      cooperative launch with the cluster list resident in LDS (lists of 4..256 chunks of 1024 clusters; same trees; measured slower) */
+    BVH_OPT_PLOC_SCHEDULER  = 3    /* 0 auto (default: = 1), 1 one launch per iteration (device-side loop, single-workgroup tail).  (ABI 4 also took 2 = a cooperative
+                                      launch with the cluster list resident in LDS: measured slower in round 4, removed in round 5 — BVH_E_INVALID_ARG now.) */
 } bvh_option;
 int  bvh_ctx_set_option(bvh_ctx* ctx, bvh_option option, int64_t value);
 int  bvh_ctx_get_option(const bvh_ctx* ctx, bvh_option option, int64_t* value_out);

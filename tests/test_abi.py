@@ -113,3 +113,42 @@ def test_emit_kernels_have_no_calls_and_the_hot_ones_no_scratch(pkg, src, tmp_pa
         for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", notes, flags=re.S):
             if "k_hploc_block" in m.group(1) or "k_hploc_ext" in m.group(1):
                 assert int(m.group(2)) == 0, (m.group(1), "spills to scratch")
+
+
+def test_split_record_load_registers_are_untouched_until_the_wait(pkg, tmp_path):
+    """common.hpp rec_load_agent_issue / rec_wait split a coherent 32-byte load and its s_waitcnt across two inline-asm statements so that other loads fly beside it; the
+    compiler does not count loads issued from inline asm, so nothing tells it that the destination VGPRs are in flight.  Checked in the LINKED code object:
+    in every kernel, between a `global_load_dwordx4 ... sc1` pair and the next `s_waitcnt vmcnt(0)` no instruction names one of the eight destination registers."""
+    got = _code_object(os.path.join(ROOT, "hip-bvh-construction_amd", "csrc", "hploc.o"), str(tmp_path))
+    if got is None:
+        pytest.skip("LLVM tools or the object file are missing")
+    dis, _ = got
+
+    def regs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    checked = 0
+    for body in re.split(r"^[0-9a-f]+ <", dis, flags=re.M)[1:]:
+        if not body.startswith("_ZN3bvh11k_hploc_ext"):
+            continue
+        lines = [l.split("//")[0].strip() for l in body.split("\n")]
+        inflight = set()
+        for l in lines:
+            toks = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+            if l.startswith("global_load_dwordx4") and l.endswith("sc1"):
+                inflight |= regs(toks[0])
+                assert not (set().union(*[regs(t) for t in toks[1:]]) & inflight), l
+                continue
+            if l.startswith("s_waitcnt") and "vmcnt(0)" in l:
+                if inflight:
+                    checked += 1
+                inflight = set()
+                continue
+            if inflight:
+                used = set().union(*[regs(t) for t in toks]) if toks else set()
+                assert not (used & inflight), f"touches a register of the in-flight record load: {l}"
+    assert checked >= 2, "the split record load was not found in k_hploc_ext (did the form change?)"

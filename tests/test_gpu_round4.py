@@ -156,10 +156,11 @@ def test_batch_keeps_every_mesh_and_pipelines_a_device(pkg, orc, ctx):
 
 @pytest.mark.parametrize("name,n", [("uniform", 4096), ("uniform", 5000), ("uniform", 33_333), ("uniform", 100_000), ("bunny", 150_000), ("sponza", 262_144), ("uniform", 262_144),
                                     ("uniform", 261_130), ("uniform", 4096 + 7), ("dups", 40_000), ("flat", 20_000), ("line", 6000), ("identical", 5000)])
-def test_ploc_resident_launch_is_bit_exact(pkg, orc, ctx, name, n):
-    """Round 4: lists of 4..256 chunks run their first iterations in ONE cooperative launch with the list resident in LDS (csrc/ploc.hip k_ploc_resident).
-    Node array, leaves and iteration count must equal the pinned oracle's byte for byte (test_ploc_bit_exact's bar) and the per-iteration path's; sizes whose last chunk is
-    shorter than the halo (4096 + 7, 261 130 = 255 x 1024 + 10) must fall back by themselves; degenerate scenes (duplicates, flat, collinear, identical) run the launch to its limits."""
+def test_ploc_chunk_boundaries_and_degenerate_scenes_bit_exact(pkg, orc, ctx, name, n):
+    """PLOC++ node array, leaves and iteration count equal the pinned oracle's byte for byte (test_ploc_bit_exact's bar) at sizes whose last chunk is shorter than the halo
+    (4096 + 7, 261 130 = 255 x 1024 + 10) and on degenerate scenes (duplicates, flat, collinear, identical: thousands of iterations, restarts of the per-iteration bookkeeping);
+    a second build of the same size (its launch batch is sized from the first) gives the same tree.  (Round 4 ran this list through a cooperative resident-launch variant too —
+    measured slower, removed in round 5: tools/probes/r05_pruned_switches.patch.)"""
     mg = pkg.meshgen
     if name == "uniform":
         tris = mg.uniform(n, 31)
@@ -178,21 +179,12 @@ def test_ploc_resident_launch_is_bit_exact(pkg, orc, ctx, name, n):
     else:
         tris = np.repeat(mg.uniform(1, 3), n)
     ref = orc.build_tree(pkg.ALGO_PLOCPP, tris)
-    outs = {}
-    for mode in ("iter", "resident"):
-        with ctx.options(ploc=mode):
-            ctx.set_profiling(2)
-            b = pkg.PLOCNew().build(ctx, tris)
-            kt = ctx.kernel_times(); ctx.set_profiling(0)
-            got = b.download()
-            outs[mode] = (got, b.timings.ploc_iterations, "k_ploc_resident" in kt)
-            assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["leaves"].tobytes() == ref["leaves"].tobytes(), (mode, name, n)
-            assert b.timings.ploc_iterations == ref["stats"]["iterations"], (mode, b.timings.ploc_iterations, ref["stats"]["iterations"])     # (also across restarts of the bookkeeping: flat / collinear scenes need thousands)
-            b2 = pkg.PLOCNew().build(ctx, tris)                       # a second build of the same size: the launch batch is sized from the first
-            assert b2.checksum() == b.checksum()
-    chunks = -(-len(tris) // 1024); last = len(tris) - (chunks - 1) * 1024
-    assert not outs["iter"][2]
-    assert outs["resident"][2] == (4 <= chunks <= 256 and last >= 16), "the resident launch runs exactly where it applies"
+    b = pkg.PLOCNew().build(ctx, tris)
+    got = b.download()
+    assert got["nodes"].tobytes() == ref["nodes"].tobytes() and got["leaves"].tobytes() == ref["leaves"].tobytes(), (name, n)
+    assert b.timings.ploc_iterations == ref["stats"]["iterations"], (b.timings.ploc_iterations, ref["stats"]["iterations"])     # (also across restarts of the bookkeeping: flat / collinear scenes)
+    b2 = pkg.PLOCNew().build(ctx, tris)
+    assert b2.checksum() == b.checksum()
 
 
 class _RawDevice:

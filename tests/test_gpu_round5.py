@@ -85,6 +85,11 @@ def _special(pkg, kind):
         t["v3"][2000, 2] = np.float32(np.nan)                        # (positive sign bit: numpy's default NaN)
     elif kind == "nan_vertex":
         t["v1"][5] = (np.nan, np.nan, np.nan)
+    elif kind == "neg_nan_coordinate":
+        t["v2"].view(np.uint32)[3000, 1] = 0xFFC00000                 # NaN with the sign bit set
+    elif kind == "ff_filled_triangle":
+        for v in ("v1", "v2", "v3"):
+            t[v].view(np.uint32)[777] = 0xFFFFFFFF                    # a triangle out of a 0xFF-filled buffer (negative NaNs with a full payload)
     elif kind == "denormals":
         for v in ("v1", "v2", "v3"):
             t[v][:] = (t[v] * np.float32(1e-41)).astype(np.float32)
@@ -93,7 +98,7 @@ def _special(pkg, kind):
     return t
 
 
-SPECIALS = ["inf_vertex", "neg_inf_vertex", "huge_triangle", "huge_offset", "nan_coordinate", "nan_vertex", "denormals"]
+SPECIALS = ["inf_vertex", "neg_inf_vertex", "huge_triangle", "huge_offset", "nan_coordinate", "nan_vertex", "neg_nan_coordinate", "ff_filled_triangle", "denormals"]
 
 
 @pytest.mark.parametrize("kind", SPECIALS)
