@@ -337,7 +337,9 @@ def main() -> None:
             roof["issue"] = {"waves_parked_frac": round(ic["SQ_WAIT_ANY"] / wc, 4),                    # at s_waitcnt / barriers: the dependent chain
                              "waves_ready_not_issued_frac": round(ic["SQ_WAIT_INST_ANY"] / wc, 4),    # lost arbitration / pipe busy
                              "waves_issuing_frac": round(ic["SQ_ACTIVE_INST_ANY"] / wc, 4),
-                             "valu_issue_slots_used_frac": round(ic["SQ_INSTS_VALU"] * 4.0 / (ic["simds"] * cyc), 4),   # one VALU instruction per SIMD quad-cycle = 1.0 (an upper bound on VALU busy)
+                             # VALU wave-instructions per SIMD per four cycles: a SIMD retires at most 2.0 full-rate (add / mul / mov: 2 cycles per wave64) or 1.0 half-rate
+                             # (min / max / compare / select / DPP / fma: 4 cycles) instructions in that time, one wave alone issues at most ~0.95 (profiles/r03_ubench_issue.md)
+                             "valu_insts_per_simd_quad_cycle": round(ic["SQ_INSTS_VALU"] * 4.0 / (ic["simds"] * cyc), 4),
                              "resident_waves_per_simd": round(wc * 4.0 / (ic["simds"] * cyc), 2),
                              "bound": "dependent chain of the PLOC rounds at the residency cap of 8 waves per SIMD (profiles/r05_att_hploc_block.md)",
                              "source": "profiles/issue_counters.json (direct SQ counter ratios)"}

@@ -124,18 +124,18 @@ __device__ __forceinline__ HpWork load_work(bool have, u32 tL, u32 tR, u32 tP, c
 }
 
 #ifndef HP_NN_LDS
-#define HP_NN_LDS 3        // neighbour selection.  3 (default since round 4): the pair's key is minimised into the FAR end's word by an LDS atomic (the reference's formulation) and into
-                           //    the lane's own running minimum by ONE v_min_f64 on the same 64-bit key (eight LDS atomics per round instead of sixteen; k_hploc_ext 0.200 -> 0.195 ms,
-                           //    tile kernel unchanged; needs -fno-slp-vectorize, see the Makefile); 1: both ends by LDS atomics (rounds 1-4); 2: own end as a compare-select chain
-                           //    on {area, slot} (measured slower); 0: round 1's alternative (two running minima in registers, the left candidates' areas through ds_bpermute)
+#define HP_NN_LDS 3        // neighbour selection.  3 (default since round 4): the pair's key is minimised into the FAR end's word by an LDS atomic (the reference's
+                           //    formulation) and into the lane's own running minimum by ONE v_min_f64 on the same 64-bit key (eight LDS atomics per round instead of
+                           //    sixteen; needs -fno-slp-vectorize, see the Makefile); 1: both ends by LDS atomics (rounds 1-3; the alt variant of tests/test_gpu_variants.py).
+                           //    (2 = own end as a compare-select chain and 0 = two running minima + ds_bpermute were measured slower: LEADS.md, tools/probes/r05_pruned_switches.patch)
 #endif
-// findNearestNeighbours (:83-117) of one PLOC round for the two tasks of a wave: every pair (slot, slot + r), r = 1..8, is evaluated ONCE, by its
-// lower end — neighbour boxes arrive through a DPP wave_shl:1 chain, two candidates per step so that the area arithmetic runs as packed f32 (same
-// operations, same association, no contraction; the min / max of the unions have no packed form) — and its 64-bit key {area bits, other end's slot} is
-// minimised into BOTH ends: the far end's word with an LDS atomic (ds_min_u64: the reference's formulation; a wave's LDS operations execute in order, so the reset,
-// the atomics and the read-back need no barrier), the lane's own minimum in a register pair (HP_NN_LDS = 3; = 1: an LDS atomic too).  Returns the slot of the
-// lane's nearest neighbour (lowest slot on equal areas).  PUBLISH: the choice is also left in the low half of the lane's key word (ploc_rounds_lds reads it there).
-// nn: the wave's 64-entry LDS scratch.  ABL_*: in-situ cost probes of tools/ab_probe.sh (wrong trees, timing only; profiles/r03_hploc_bound.md).
+// findNearestNeighbours (:83-117) of one PLOC round for the two tasks of a wave: every pair (slot, slot + r), r = 1..8, is evaluated ONCE, by its lower end —
+// neighbour boxes arrive through a DPP wave_shl:1 chain, one candidate per step in scalar f32 (a packed f32 operation costs what two scalar ones do on gfx950 and the
+// two-candidate form kept twelve more registers alive) — and its 64-bit key {area bits, other end's slot} is minimised into BOTH ends: the far end's word with an LDS
+// atomic (ds_min_u64: a wave's LDS operations execute in order, so the reset, the atomics and the read-back need no barrier), the lane's own minimum in a register
+// pair (HP_NN_LDS = 3; = 1: an LDS atomic too).  Returns the slot of the lane's nearest neighbour (lowest slot on equal areas).  PUBLISH: the choice is also left in
+// the low half of the lane's key word (ploc_rounds_lds reads it there).  nn: the wave's 64-entry LDS scratch.  ABL_EXTRA_*: in-situ cost probes (wrong trees, timing
+// only; profiles/r04_tile_phases.md).
 template <bool PUBLISH = false>
 __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int lane, int slot, u64* nn) {
     nn[lane] = ~0ull;
@@ -147,8 +147,6 @@ __device__ __forceinline__ int nn_search(const Box& b, bool act, u32 cnt, int la
     // compared, not flushed (the f64 denormal mode of every HIP kernel is "preserve"), and a minimum returns one of its operands bit for bit.
     double own = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
 #endif
-    // one candidate per step, scalar f32 (a packed f32 operation costs what two scalar ones do on gfx950 — profiles/r03_ubench_issue.md — and the
-    // two-candidate form keeps twelve more registers alive): the same operations in the same association
     Box nb = b;
 #pragma unroll
     for (int rr = 1; rr <= HP_RADIUS; ++rr) {
@@ -586,7 +584,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     constexpr int NLEV = KeyBits<K>::value;          // hierarchy levels = bits of the augmented key (64 / 96)
     constexpr int KM = 18;                           // key margin: the hand-over probes up to 17 leaves beyond the tile's rims (small children of external
 #ifndef HPB_WIDE
-#define HPB_WIDE 0       // A/B switch (off: measured, no gain — DESIGN.md section 9 row 64).  1: a round in which only one half of the wave still has a task runs that task on the whole wave (nn_search_wide: four candidates per lane)
+#define HPB_WIDE 0       // A/B switch (off: measured, no gain — LEADS.md row 64).  1: a round in which only one half of the wave still has a task runs that task on the whole wave (nn_search_wide: four candidates per lane)
 #endif
                          //    needed 70: spills in the rounds); since the rounds no longer keep a task's box and tag alive for a store behind the loop (ploc_rounds_lds: the
                          //    left-pack of a task that needs no round runs up front; 70 -> 66 VGPRs, tile kernel 0.644 -> 0.633 ms by itself) the kernel fits 64 registers with
@@ -873,7 +871,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                     if (dep_arrive(dep, pc, dep_word(3u - e, lbig ? 0u : lo, rbig ? 0u : hi), L, R)) ready_push(pc, L, R);
                 }
             } else if (rg != 0u) {                   // local big node
-                const u32 L = g0 + (rg & 0x3FFFu), R = g0 + ((rg >> 16) & 0x3FFFu);         // (bits 30..31: HPB_DEPS arrival count)
+                const u32 L = g0 + (rg & 0x3FFFu), R = g0 + ((rg >> 16) & 0x3FFFu);         // (bits 30..31 unused)
                 const bool pleft = (rg & 0x8000u) != 0u;
                 const u32 q = pleft ? L - 1u : R;
                 if (q < g0 || m_is_ext(m_range[q - g0])) s_task[atomicAdd(&s_npub, 1u)] = (unsigned short)(k | (pleft ? 0x8000u : 0u));

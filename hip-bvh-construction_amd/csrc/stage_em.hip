@@ -78,8 +78,10 @@ __global__ __launch_bounds__(EX_BLOCK) void k_extents(const float4* __restrict__
         const float  c = reinterpret_cast<const float*>(tris + (size_t)i * 4 + 2)[0];
         // v1 = (a.x,a.y,a.z)  v2 = (a.w,b.x,b.y)  v3 = (b.z,b.w,c)
         Box bx;
-        bx.lx = fminf(fminf(a.x, a.w), b.z); bx.ly = fminf(fminf(a.y, b.x), b.w); bx.lz = fminf(fminf(a.z, b.y), c);
-        bx.hx = fmaxf(fmaxf(a.x, a.w), b.z); bx.hy = fmaxf(fmaxf(a.y, b.x), b.w); bx.hz = fmaxf(fmaxf(a.z, b.y), c);
+        // (Aabb() is the reset box and grow() is fminf / fmaxf, src/Common.h:327-345: a triangle whose three coordinates on an axis are all NaN — or all +inf — keeps
+        // +-FltMax there; tests/test_gpu_round5.py ff_filled_triangle found the difference against the reference's kernel)
+        bx.lx = fminf(FMAX, fminf(fminf(a.x, a.w), b.z)); bx.ly = fminf(FMAX, fminf(fminf(a.y, b.x), b.w)); bx.lz = fminf(FMAX, fminf(fminf(a.z, b.y), c));
+        bx.hx = fmaxf(-FMAX, fmaxf(fmaxf(a.x, a.w), b.z)); bx.hy = fmaxf(-FMAX, fmaxf(fmaxf(a.y, b.x), b.w)); bx.hz = fmaxf(-FMAX, fmaxf(fmaxf(a.z, b.y), c));
         box_store(boxes + i, bx);
         acc = box_union(acc, bx);
     }
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(EM_BLOCK) void k_extents_packed(const float* __rest
         if (threadIdx.x < cnt) {
             const float* t = s_t + threadIdx.x * 9;
             Box bx;
-            bx.lx = fminf(fminf(t[0], t[3]), t[6]); bx.ly = fminf(fminf(t[1], t[4]), t[7]); bx.lz = fminf(fminf(t[2], t[5]), t[8]);
-            bx.hx = fmaxf(fmaxf(t[0], t[3]), t[6]); bx.hy = fmaxf(fmaxf(t[1], t[4]), t[7]); bx.hz = fmaxf(fmaxf(t[2], t[5]), t[8]);
+            bx.lx = fminf(FMAX, fminf(fminf(t[0], t[3]), t[6])); bx.ly = fminf(FMAX, fminf(fminf(t[1], t[4]), t[7])); bx.lz = fminf(FMAX, fminf(fminf(t[2], t[5]), t[8]));
+            bx.hx = fmaxf(-FMAX, fmaxf(fmaxf(t[0], t[3]), t[6])); bx.hy = fmaxf(-FMAX, fmaxf(fmaxf(t[1], t[4]), t[7])); bx.hz = fmaxf(-FMAX, fmaxf(fmaxf(t[2], t[5]), t[8]));
             box_store(boxes + base + threadIdx.x, bx);
             acc = box_union(acc, bx);
         }
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(EX_BLOCK) void k_extents_indexed(const float* __res
         if (i0 >= n_verts) i0 = 0; if (i1 >= n_verts) i1 = 0; if (i2 >= n_verts) i2 = 0;   // never read out of bounds
         const float* a = verts + (size_t)i0 * 3; const float* b = verts + (size_t)i1 * 3; const float* c = verts + (size_t)i2 * 3;
         Box bx;
-        bx.lx = fminf(fminf(a[0], b[0]), c[0]); bx.ly = fminf(fminf(a[1], b[1]), c[1]); bx.lz = fminf(fminf(a[2], b[2]), c[2]);
-        bx.hx = fmaxf(fmaxf(a[0], b[0]), c[0]); bx.hy = fmaxf(fmaxf(a[1], b[1]), c[1]); bx.hz = fmaxf(fmaxf(a[2], b[2]), c[2]);
+        bx.lx = fminf(FMAX, fminf(fminf(a[0], b[0]), c[0])); bx.ly = fminf(FMAX, fminf(fminf(a[1], b[1]), c[1])); bx.lz = fminf(FMAX, fminf(fminf(a[2], b[2]), c[2]));
+        bx.hx = fmaxf(-FMAX, fmaxf(fmaxf(a[0], b[0]), c[0])); bx.hy = fmaxf(-FMAX, fmaxf(fmaxf(a[1], b[1]), c[1])); bx.hz = fmaxf(-FMAX, fmaxf(fmaxf(a[2], b[2]), c[2]));
         box_store(boxes + i, bx);
         acc = box_union(acc, bx);
     }
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict_
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
 #ifndef EM_PPT
-#define EM_PPT 4         // primitives per thread of the grid-stride kernels below their workgroup caps (A/B: 2 / 1 measured at 262 144)
+#define EM_PPT 4         // primitives per thread of the grid-stride kernels below their workgroup caps (A/B: 2 / 1 measured at 262 144, LEADS.md)
 #endif
 #ifndef EX_PPT
 #define EX_PPT 4
