@@ -204,6 +204,9 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
 #ifndef PLOC_OCC
 #define PLOC_OCC 5
 #endif
+#ifndef PLOC_STATIC_G
+#define PLOC_STATIC_G 256     // largest grid that takes static chunk ids (0: tickets always)
+#endif
 // One iteration as workgroup `wg` of `G`.  Returns true when the build is over (one cluster left, or this workgroup has nothing more to do in it).
 template <int PL_BLOCK, bool FIRST>
 __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restrict__ list_in, float4* __restrict__ list_out, bvh2_node* __restrict__ nodes,
@@ -211,10 +214,27 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
                                                const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
                                                const u32 wg, const u32 G) {
     constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
+    constexpr int SPT = (PL_SPAN + PL_BLOCK - 1) / PL_BLOCK;
+    const int tid = tid_x();
+    // Static chunk ids (round 5).  A grid of at most PLOC_STATIC_G workgroups is resident as a whole (one 1024-thread workgroup per CU at most), so chunk = workgroup id
+    // needs no ticket to keep the look-back free of deadlock — and the chunk's list entries can be requested BEFORE the cluster count is known: the count (a scalar
+    // load of what the previous launch wrote), the ticket (a returning atomic + two barriers) and the entries were three dependent round trips at the start of every
+    // iteration's ~7 us.  Used when the grid turns out to cover the iteration's chunks (G >= chunks: every late iteration, every iteration below 256 chunks); the
+    // speculative entries of positions beyond the count are masked like any halo position.  Otherwise the ticket path runs unchanged.
+    u32 sid_[SPT]; Box sb_[SPT];
+    const bool spec = !FIRST && PL_BLOCK == 1024 && G <= (u32)PLOC_STATIC_G;       // (the 512-thread shape serves the early iterations of large inputs: thousands of chunks)
+    if (spec) {
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int k = tid + q * PL_BLOCK;
+            const long long gpos = (long long)wg * PLOC_CHUNK - PL_HALO + k;
+            const size_t gc = (k < PL_SPAN && gpos >= 0 && gpos <= (long long)ni) ? (size_t)gpos : (size_t)wg * PLOC_CHUNK;      // (inside the list's n entries: G <= ceil(n / 1024))
+            entry_load(list_in, gc, sid_[q], sb_[q]);
+        }
+    }
     const u32 C = counts[0];
     auto set_count = [&](u32 v) { counts[1] = v; };
-    if (C <= 1) { if (wg == 0 && tid_x() == 0) set_count(C); return true; }
-    const int tid = tid_x();
+    if (C <= 1) { if (wg == 0 && tid == 0) set_count(C); return true; }
     // cluster at list position g: from the list, or (FIRST) leaf g itself; own = g belongs to this chunk (not its halo): write the PrimRef
     auto fetch = [&](size_t g, bool own, u32& id, Box& b) {
         if (FIRST) {
@@ -343,18 +363,22 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
             ex += ((u32)mrg[q] << 16) + (u32)keep[q];
         }
     };
+    const bool stat = spec && G >= chunks;                 // (grid-uniform)
     for (u32 trip = 0; ; ++trip) {
-        __syncthreads();
-        if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
-        __syncthreads();
-        const u32 chunk = s.bcast[0];
+        u32 chunk;
+        if (stat) chunk = wg;                             // (one trip: the one-shot rule below ends the loop)
+        else {
+            __syncthreads();
+            if (tid == 0) s.bcast[0] = atomicAdd(tickets, 1u);
+            __syncthreads();
+            chunk = s.bcast[0];
+        }
         if (chunk >= chunks) break;
         const long long o = (long long)chunk * PLOC_CHUNK;
         // span entry k <-> list position o - HALO + k   (:232-249)
         {   // All of a thread's span entries are requested before the first is waited for (clamped positions, no branch around the loads): the loop over the span — two
             // trips for the 1024-thread shape, the second one for the 64 halo entries only — came out as load, wait, load, wait: a second dependent memory round trip
             // in every iteration's ~10 us, spent by one wave while fifteen wait at the barrier (round 4, found in the ISA).
-            constexpr int SPT = (PL_SPAN + PL_BLOCK - 1) / PL_BLOCK;
             u32 id_[SPT]; Box b_[SPT]; bool in_[SPT]; u32 prim_[SPT];
 #pragma unroll
             for (int q = 0; q < SPT; ++q) {
@@ -362,7 +386,9 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
                 const long long gpos = o - PL_HALO + k;
                 in_[q] = k < PL_SPAN && gpos >= 0 && gpos < (long long)C;
                 const size_t gc = in_[q] ? (size_t)gpos : (size_t)o;                 // (o < C: the chunk exists)
-                if (FIRST) prim_[q] = svals[gc]; else entry_load(list_in, gc, id_[q], b_[q]);
+                if (FIRST) prim_[q] = svals[gc];
+                else if (stat) { id_[q] = sid_[q]; b_[q] = sb_[q]; }                   // requested at the top, beside the count
+                else entry_load(list_in, gc, id_[q], b_[q]);
             }
             if (FIRST) {
 #pragma unroll
@@ -420,7 +446,7 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
         // `chunks` different workgroups, so nobody needs to ask again just to learn that the list is used up — the finish below starts a round trip earlier
         // Measured on the MI355X (whole build, same box): Sponza-like 262 144 0.4107 -> 0.4065 ms, 524 288 0.5216 -> 0.5180, uniform 1 M 0.5630 -> 0.5605; but 2 M
         // 0.783 -> 0.790 and 10 M 2.206 -> 2.245 (there the second ticket's round trip is what gives the predecessors time to publish before the walk): small inputs only
-        if (G >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N) break;            // (grid-uniform)
+        if (stat || (G >= chunks && ni < (u32)PLOC_ONE_SHOT_MAX_N)) break;  // (grid-uniform; a static chunk id is good for exactly one trip)
     }
     if (p_have) { __syncthreads(); finish(p_chunk, p_tot, p_ex, p_cid, p_pid, p_cb, p_mrg, p_keep); }
     return false;
