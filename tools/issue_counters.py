@@ -29,7 +29,9 @@ def main():
         if k.startswith("_"):
             continue
         cyc = e["SQ_BUSY_CYCLES"] / 32
-        print(k, "valu_busy %.3f  lds_busy %.3f  parked %.3f" % (e["SQ_INSTS_VALU"] * e["cycles_per_valu_inst"] / (1024 * cyc), e["SQ_INSTS_LDS"] * e["cycles_per_lds_inst"] / (256 * cyc), e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]))
+        wc = e["SQ_WAVE_CYCLES"]
+        print(k, "waves parked %.3f  ready-not-issued %.3f  issuing %.3f  | VALU instructions per SIMD quad-cycle %.3f  | resident waves per SIMD %.2f" % (
+            e["SQ_WAIT_ANY"] / wc, e["SQ_WAIT_INST_ANY"] / wc, e["SQ_ACTIVE_INST_ANY"] / wc, e["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), wc * 4.0 / (1024 * cyc)))
     if len(sys.argv) > 3:
         import os
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

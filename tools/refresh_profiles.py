@@ -3,7 +3,7 @@
 (bench line, kernel trace, HBM traffic, SQ counters) from them.  python tools/refresh_profiles.py [r04]"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 O = os.path.join(ROOT, "gpurun_out", "prof_round"); P = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, f"{rnd}_bench.json"))
 for f in ("pmc_traffic.json", "issue_counters.json", "rocprof_kernel_avg.json"): shutil.copy(os.path.join(O, f), os.path.join(P, f))
@@ -19,6 +19,6 @@ sec = ["## bench line (`profiles/%s_bench.json`)\n\n" % rnd,
        "`secondary`:\n" + "".join("* %s\n" % json.dumps(x) for x in b["secondary"]) + "\n",
        "## rocprofv3 --kernel-trace --stats (the bench command itself without its CPU leg and secondary loops: 206 builds = 5 warm-up + 200 timed + 1 stage-timed)\n\n" + open(os.path.join(O, "stats.md")).read().strip() + "\n\n",
        "## HBM traffic per build (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KB units; MI355X_MICROARCH.md's gfx950 correction)\n\n" + open(os.path.join(O, "traffic.md")).read().strip() + "\n\n",
-       "## issue (SQ counters, priced: profiles/r04_direct_counters.md for the direct ones)\n\n" + open(os.path.join(O, "issue.md")).read().strip() + "\n\n"]
+       "## issue (SQ counters of the bench command: direct ratios)\n\n" + open(os.path.join(O, "issue.md")).read().strip() + "\n\n"]
 open(path, "w").write(s[:i0] + "".join(sec) + s[i1:])
 print(b["value"], b["ms_per_step"], b["kernel_ms_per_step"], rf["frac"], rf.get("frac_rocprof"))
