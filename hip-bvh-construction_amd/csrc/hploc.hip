@@ -728,7 +728,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             {   int a = p + 1, b = jmax;                                         // last inside position in [p+1, jmax]
                 while (a < b) { const int mid = (a + b + 1) >> 1; if (inside(mid)) a = mid; else b = mid - 1; }
                 hi = a; }
+#ifdef HPB_CUT            // measurement build (LEADS.md rows 15, 84): local nodes of more than HPB_CUT leaves are handed to k_hploc_ext like the nodes that cross the tile
+            const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u) || (hi - lo + 1) > (int)(HPB_CUT);
+#else
             const bool ext = lo < (int)g0 || hi > (int)(g0 + (u32)T - 1u);
+#endif
             m_range[k] = 0u;
             if (ext) {
                 // An external node's own contribution to its dependency word (the hand-over adds it): which children are big — child [L, p] iff leaf p - 16 shares

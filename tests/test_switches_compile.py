@@ -19,9 +19,9 @@ SETS = [
     # the alt variant that tests/test_gpu_variants.py also RUNS (same trees), and the measurement builds behind profiles/ (round clock, tile phases, sensitivity probes)
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DHP_NN_LDS=1", "-DHPB_WIDE=1"]),
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DBVH_ABLATION", "-DABL_ROUND_CLOCK", "-DABL_LDS_PAD=16384", "-DABL_TILE_PHASES=2"]),
-    ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DBVH_ABLATION", "-DABL_EXTRA_VALU", "-DABL_EXTRA_BPERM", "-DABL_EXTRA_TRIP", "-DABL_EXT_TRACE", "-DHPB_OCC=7", "-DHPX_OCC=5"]),
+    ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DBVH_ABLATION", "-DABL_EXTRA_VALU", "-DABL_EXTRA_BPERM", "-DABL_EXTRA_TRIP", "-DABL_EXT_TRACE", "-DHPB_OCC=7", "-DHPX_OCC=5", "-DHPB_CUT=128"]),
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DBVH_ABLATION", "-DABL_EXT_TIMING"]),
-    ("ploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DPLOC_NN_OWN_F64=0", "-DPLOC_TAIL_PAIRS=0", "-DPLOC_ABL=1", "-DPLOC_OCC=4"]),
+    ("ploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DPLOC_NN_OWN_F64=0", "-DPLOC_TAIL_PAIRS=0", "-DPLOC_ABL=1", "-DPLOC_OCC=4", "-DPLOC_STATIC_G=0"]),
     ("sort.hip", [], ["-DBVH_ABLATION", "-DSORT_WIDE_IPT=12", "-DSORT_HELP_AFTER=64u"]),
     ("lbvh.hip", EMIT, ["-DLBVH_EXT_MAX_SHIFT=6", "-DBVH_ABLATION"]),
     ("api.hip", [], ["-DSORT_GATE_TOP=0", "-DBVH_ABLATION"]),
@@ -43,8 +43,8 @@ def test_no_unlisted_switch():
     import re
     known = {  # tunables (#ifndef X / #define X default) and the measurement flags
         "BVH_ABLATION", "HP_NN_LDS", "HPB_WIDE", "HPA_OCC", "HPB_OCC", "HPB_OCC_1024", "HPB_OCC64", "HPX_OCC", "HPB_T", "HPB_NT", "HPX_GRID",
-        "ABL_ROUND_CLOCK", "ABL_LDS_PAD", "ABL_TILE_PHASES", "ABL_EXTRA_VALU", "ABL_EXTRA_BPERM", "ABL_EXTRA_TRIP", "ABL_EXT_TRACE", "ABL_EXT_TIMING",
-        "PLOC_NARROW", "PLOC_NN_OWN_F64", "PLOC_TAIL_PAIRS", "PLOC_ONE_SHOT_MAX_N", "PLOC_ABL", "PLOC_OCC",
+        "ABL_ROUND_CLOCK", "ABL_LDS_PAD", "HPB_CUT", "ABL_TILE_PHASES", "ABL_EXTRA_VALU", "ABL_EXTRA_BPERM", "ABL_EXTRA_TRIP", "ABL_EXT_TRACE", "ABL_EXT_TIMING",
+        "PLOC_NARROW", "PLOC_NN_OWN_F64", "PLOC_TAIL_PAIRS", "PLOC_ONE_SHOT_MAX_N", "PLOC_ABL", "PLOC_OCC", "PLOC_STATIC_G",
         "SORT_HELP_AFTER", "SORT_WIDE_IPT", "BVH_SORT_IPT", "BVH_SORT_WIDE_MIN_N", "SORT_GATE_TOP", "LEAF_FROM_TRIS",
         "EM_PPT", "EX_PPT", "MORTON_GROUP", "MORTON64_GROUP", "SORT_HIST_GROUP", "LBVH_TILE_SIZE", "LBVH_EXT_MAX_SHIFT", "__x86_64__"}
     found = set()
