@@ -15,7 +15,9 @@
 // tests/test_reference_kernels.py compares them with this file on the GPU box — and (3) the reference's PLOC++ kernels (SetupClusters, Ploc,
 // SinglePassPloc) and both CollapseToWide4Bvh kernels executed on the CPU under the fiber SIMT emulator of tools/oracle/ref_emulator.cpp
 // (oracle/_ref/libref_ploc_emu.so, libref_lbvh_emu.so; outputs committed in tests/golden/reference_outputs.json): orc_ploc's node arrays
-// equal the emulated reference's byte for byte, orc_collapse4's wide trees its topology and cost.  The radix sort
+// equal the emulated reference's byte for byte, orc_collapse4's wide trees its topology and cost — and (4, round 5) the reference's own wave64 build of
+// CalculateSceneExtents, Ploc, SinglePassPloc and both CollapseToWide4Bvh kernels executed on the MI355X (oracle/_ref/*.w64.co, `_ploc_hw` goldens,
+// tests/test_reference_w64.py, tests/test_oracle_golden.py).  The radix sort
 // (Orochi, un-vendored submodule, version unknown) has no reference-side pin: "parity unpinned" for
 // the sort boundary; the contract adopted is a stable ascending sort of the 32-bit key.
 //

@@ -2,8 +2,9 @@
 // lie under /root/reference (by path, never copied into the repository).  TEST INFRASTRUCTURE ONLY (dev container; the reference tree does not
 // exist on the GPU box).  Compiled three times by oracle/Makefile:
 //   -DREF_FLAVOUR_PLOC  src/Ploc++Kernel.h: SetupClusters, Ploc, SinglePassPloc driven by a restatement of the host loop (src/PLOC++Bvh.cpp:82-152) —
-//                       the reference's Ploc kernel cannot run on wave64 hardware (WarpSize is hard-coded to 32 for gfx950, src/Common.h:100-106), so this
-//                       is its only executable form here — and its CollapseToWide4Bvh (:364-465; host set-up src/PLOC++Bvh.cpp:154-190);
+//                       the wave32 flavour (src/Common.h:100-106 without a gfx9 macro); since round 5 the reference's own wave64 flavour of the same kernels also
+//                       runs on the MI355X (oracle/_ref/*.w64.co, tests/test_reference_w64.py), so this is a second, independent reading — and its
+//                       CollapseToWide4Bvh (:364-465; host set-up src/PLOC++Bvh.cpp:154-190);
 //   -DREF_FLAVOUR_LBVH  src/TwoPassLbvhKernel.h: CollapseToWide4Bvh (:237-336; host set-up src/TwoPassLbvh.cpp:154-183).
 //   -DREF_FLAVOUR_HPLOC src/HplocKernel.h: SetupClusters + HPloc (host: src/Hploc.cpp:83-121).  This flavour exists to CHECK THE EMULATOR, not the oracle: the
 //                       same header also runs UNMODIFIED on the MI355X (oracle/_ref/HplocKernel*.co through oracle/ref_driver.cpp), and it speaks the
