@@ -162,3 +162,41 @@ def test_tile_schedulers_at_odd_sizes(pkg, orc, ctx, n, kind):
         elif algo == 3:
             hn, hl, _ = orc.hploc(fe["boxes"], fe["skeys"], fe["svals"])
             assert got["leaves"].tobytes() == hl.tobytes() and orc.topology_hash(got["nodes"], got["leaves"], 0, n, 1) == orc.topology_hash(hn, hl, 0, n, 1)
+
+
+def test_reference_kernels_at_the_headline_size(pkg, orc, ctx, big):
+    """Round 5: the reference's OWN kernels at BASELINE.json's headline size on the MI355X, not only the oracle's goldens — `CalculateSceneExtents` (wave64 build),
+    `CalculateMortonCodes`, `InitBvhNodes` + `BvhBuildAndFit`, and `SetupClusters` + `HPloc` (contraction off) on uniform(10 M, 1): boxes / scene / keys / single-pass
+    LBVH node array byte for byte, HPLOC leaves byte for byte and canonical topology, against the PRODUCT's build of the same mesh."""
+    from conftest import require_ref
+    require_ref(os.path.exists(orc.REF_DRIVER), "oracle/_ref/libref_driver.so (the reference's kernels)")
+    n = len(big)
+    boxes_ref, scene_ref = orc.ref_extents(big, nofma=True)
+    keys_ref, _ = orc.ref_morton(boxes_ref, scene_ref, nofma=True)
+    order = np.argsort(keys_ref, kind="stable").astype(np.uint32); skeys = keys_ref[order]
+    b1 = pkg.SinglePassLbvh().build(ctx, big); g1 = b1.download()
+    assert g1["scene"].tobytes() == scene_ref.tobytes()
+    assert np.array_equal(g1["sorted_keys"], skeys) and np.array_equal(g1["sorted_vals"], order)
+    nodes1, root1 = orc.ref_lbvh_single(big, skeys, order, nofma=True)
+    assert g1["root"] == root1 and g1["nodes"].tobytes() == nodes1.tobytes(), "single-pass LBVH at 10 M != the reference's kernels"
+    del nodes1, g1
+    h_nodes, h_leaves, merged = orc.ref_hploc(boxes_ref, skeys, order, nofma=True, cover_all=(n - 1) % 32 == 0)
+    assert merged == n - 1
+    t_ref = orc.topology_hash(h_nodes, h_leaves, 0, n, 1)
+    for mode in ("block", "async"):
+        with ctx.options(hploc=mode):
+            g3 = pkg.HPLOC().build(ctx, big).download()
+        assert g3["leaves"].tobytes() == h_leaves.tobytes()
+        assert orc.topology_hash(g3["nodes"], g3["leaves"], 0, n, 1) == t_ref, f"HPLOC ({mode}) at 10 M != the reference's HPloc kernel on the MI355X"
+
+
+def test_reference_ploc_kernels_at_config5_size(pkg, orc, ctx):
+    """the reference's Ploc / SinglePassPloc kernels (wave64 build, host loop with its per-iteration read-back) on uniform(2 M, 100) — config 5's first mesh — against the product"""
+    from conftest import require_ref
+    require_ref(os.path.exists(orc.REF_DRIVER), "oracle/_ref/libref_driver.so (the reference's kernels)")
+    tris = pkg.meshgen.uniform(2_000_000, 100); n = len(tris)
+    fe = orc.front_end(tris)
+    p_nodes, p_leaves, p_iters = orc.ref_ploc(fe["boxes"], fe["svals"], nofma=True)
+    b = pkg.PLOCNew().build(ctx, tris); g = b.download()
+    assert g["leaves"].tobytes() == p_leaves.tobytes() and b.timings.ploc_iterations == p_iters
+    assert orc.topology_hash(g["nodes"], g["leaves"], 0, n, 1) == orc.topology_hash(p_nodes, p_leaves, 0, n, 1), "PLOC++ at 2 M != the reference's Ploc kernels on the MI355X"
