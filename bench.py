@@ -67,15 +67,48 @@ def _load_json(name):
 
 
 def kernel_source_hash() -> str:
-    """sha256[:16] over the kernel sources: the committed counter files (profiles/*.json written by tools/prof_round.sh) carry the hash of the sources they were
-    measured on, so that a line can say whether its static inputs (PMC traffic, SQ counters, task share) belong to the kernels it timed"""
+    """sha256[:16] over the gfx950 machine code (.text of every code object) inside the library this process measures: the committed counter files (profiles/*.json
+    written by tools/prof_round.sh) carry the hash of the kernels they were measured on, so that a line can say whether its static inputs (PMC traffic, SQ counters,
+    rocprof averages) belong to the kernels it timed.  Round 5 hashed the source text, and a default-off #ifdef line added after the profile run marked three unchanged
+    profiles stale; the machine code does not change for text the preprocessor drops.  (Falls back to the source text if the library cannot be parsed.)"""
     import hashlib
+    import struct
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "hip-bvh-construction_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")) or f == "Makefile":       # (the compile flags are part of what was measured: round 4)
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    try:
+        import bvh_pkg
+        d = open(bvh_pkg.load().LIB_PATH, "rb").read()
+
+        def sections(elf):      # ELF64 little endian: name -> (offset, size)
+            shoff = struct.unpack_from("<Q", elf, 0x28)[0]; entsize, num, strndx = struct.unpack_from("<HHH", elf, 0x3A)
+            raw = [struct.unpack_from("<IIQQQQ", elf, shoff + i * entsize) for i in range(num)]
+            stro = raw[strndx][4]
+            return {elf[stro + r[0]: elf.index(b"\0", stro + r[0])].decode(): (r[4], r[5]) for r in raw}
+        off, size = sections(d)[".hip_fatbin"]
+        fat = d[off: off + size]
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        found = 0
+        at = fat.find(magic)
+        while at >= 0:
+            n_entries = struct.unpack_from("<Q", fat, at + len(magic))[0]
+            q = at + len(magic) + 8
+            for _ in range(n_entries):
+                eoff, esize, tsize = struct.unpack_from("<QQQ", fat, q)
+                triple = fat[q + 24: q + 24 + tsize].decode(); q += 24 + tsize
+                if "gfx950" in triple and esize:
+                    co = fat[at + eoff: at + eoff + esize]
+                    toff, tlen = sections(co)[".text"]
+                    h.update(co[toff: toff + tlen]); found += 1
+            at = fat.find(magic, at + len(magic))
+        if not found:
+            raise ValueError("no gfx950 code object")
+        return h.hexdigest()[:16]
+    except Exception:
+        h = hashlib.sha256()
+        d = os.path.join(ROOT, "hip-bvh-construction_amd", "csrc")
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".hpp")) or f == "Makefile":
+                h.update(open(os.path.join(d, f), "rb").read())
+        return "src-" + h.hexdigest()[:12]
 
 
 def run_secondary(pkg, torch, local):
@@ -341,8 +374,9 @@ def main() -> None:
                              # (min / max / compare / select / DPP / fma: 4 cycles) instructions in that time, one wave alone issues at most ~0.95 (profiles/r03_ubench_issue.md)
                              "valu_insts_per_simd_quad_cycle": round(ic["SQ_INSTS_VALU"] * 4.0 / (ic["simds"] * cyc), 4),
                              "resident_waves_per_simd": round(wc * 4.0 / (ic["simds"] * cyc), 2),
-                             "bound": "dependent chain of the PLOC rounds at the residency cap of 8 waves per SIMD (profiles/r05_att_hploc_block.md)",
                              "source": "profiles/issue_counters.json (direct SQ counter ratios)"}
+            if name == "k_hploc_block":       # (the account of what bounds THIS kernel; other dominant kernels carry the counters only)
+                roof["issue"]["bound"] = "dependent chain of the PLOC rounds at the residency cap of 8 waves per SIMD (profiles/r05_att_hploc_block.md)"
             roof["profiles_match_kernel_sources"]["issue_counters"] = (_load_json("issue_counters.json") or {}).get("_kernel_source_hash") == src_hash
         if name in KERNEL_OWN_BYTES_PER_PRIM:     # the same kernel against the bytes it really has to move (work lists stay in LDS)
             own = KERNEL_OWN_BYTES_PER_PRIM[name] * n
@@ -372,7 +406,8 @@ def main() -> None:
                    "seed": "1+rank", "parallelism": f"scene-shard x{world}" + (" + allgather(root aabb)" if world > 1 else "")},
         "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         "kernel_ms_per_step": {k: round(v[0] / n_sampled, 4) for k, v in ktimes.items()},     # from the sampled builds of the timed region
-        "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds, the first timed build included" + (f" ({n_sampled} builds)" if sample_every > 1 else ""),
+        "kernel_event_sampling": f"every {sample_every}th of the {args.steps} timed builds, the first timed build included" + (f" ({n_sampled} builds)" if sample_every > 1 else "")
+                                 + "; a sampled build carries one event per launch and is stretched by them: the sum of kernel_ms_per_step exceeds ms_per_step",
         "sah_bvh2": round(sah, 4),
         "pipeline_roofline": {"algorithmic_bytes": pipeline_bytes, "source": ("exact: " + ex[3]) if ex else "SURVEY.md 8(d) constants (bvh_timings.bytes_algorithmic)",
                               "achieved_GBs": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 1),

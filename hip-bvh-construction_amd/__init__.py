@@ -103,7 +103,7 @@ ABI_VERSION = 4                      # BVH_ABI_VERSION of include/bvh_mi355x.h t
 # bvh_option (bvh_ctx_set_option) and the names this harness accepts for the values
 OPT_HPLOC_SCHEDULER, OPT_LBVH_SCHEDULER, OPT_SORT_TEST_KNOBS, OPT_PLOC_SCHEDULER = 0, 1, 2, 3
 _OPTION_IDS = {"hploc": OPT_HPLOC_SCHEDULER, "lbvh": OPT_LBVH_SCHEDULER, "sort_knobs": OPT_SORT_TEST_KNOBS, "ploc": OPT_PLOC_SCHEDULER}
-_OPTION_VALUES = {"auto": 0, "default": 0, None: 0, "async": 1, "single": 1, "iter": 1, "block": 2, "tiles": 2}
+_OPTION_VALUES = {"auto": 0, "default": 0, None: 0, "async": 1, "single": 1, "iter": 1, "block": 2, "tiles": 2, "live": 3, "overlapped": 3}
 
 
 class BuildInput(C.Structure):

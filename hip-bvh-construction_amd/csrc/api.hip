@@ -79,6 +79,9 @@ struct bvh_ctx {
     uint64_t collapse_last_key = 0;                           // ... of this KIND: {node layout, root index} — an LBVH and a PLOC tree of one size have different level widths
     uint32_t collapse_last_len[COLLAPSE_MAX_BATCH] = {0};     // ... and their task counts (grid sizes of the first batch's launches),
     int collapse_len_batch = 0;                               //     valid for that many levels (0: the previous collapse took several batches)
+    hipStream_t side = nullptr;       // the overlapped HPLOC schedule's consumer stream (k_hploc_live), with its fork / join events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool queue_items_stale = false;   // the classic tile schedule leaves its queue items behind; the overlapped one needs (and leaves) the slots all-zero
     int64_t options[4] = {0, 0, 0, 0}; // bvh_option values (bvh_ctx_set_option); all default 0 = decide by input size / no test knobs
 };
 
@@ -92,13 +95,33 @@ inline bool hploc_use_block(const bvh_ctx* c, uint32_t n) {
     if (n <= 2 * hploc_block_tile()) return false;     // the root must cross tiles
     const int64_t o = c->options[BVH_OPT_HPLOC_SCHEDULER];   // 1 async / 2 tiles: the host's override (A/B measurements, tests)
     if (o == 1) return false;
-    if (o == 2) return true;
+    if (o == 2 || o == 3) return true;
     return n >= HPLOC_BLOCK_MIN_N;
+}
+// ... and from this size on the external climb runs beside the tile kernel on the side stream (k_hploc_live) instead of behind it
+#ifndef HPLOC_LIVE_MIN_N
+#define HPLOC_LIVE_MIN_N 800000
+#endif
+inline bool hploc_use_live(const bvh_ctx* c, uint32_t n) {
+    const int64_t o = c->options[BVH_OPT_HPLOC_SCHEDULER];
+    if (o == 2) return false;
+    if (o == 3) return true;
+    return n >= (uint32_t)HPLOC_LIVE_MIN_N;
 }
 // HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
 void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves,
                 bool heads_cleared = false) {
-    if (hploc_use_block(c, n)) launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc, heads_cleared);
+    if (hploc_use_block(c, n)) {
+        const bool live = hploc_use_live(c, n) && c->side;
+        const HplocLive lv{ c->side, c->ev_fork, c->ev_join };
+        if (live && c->queue_items_stale) {      // (only after a switch of schedules on one context, or a build that failed half-way)
+            (void)hipMemsetAsync(c->hploc.queue_pc, 0, c->hploc.queue_capacity * sizeof(u32), s);
+            (void)hipMemsetAsync(c->hploc.queue_rng, 0, c->hploc.queue_capacity * sizeof(u64), s);
+            c->queue_items_stale = false;
+        }
+        if (!live) c->queue_items_stale = true;
+        launch_hploc_block(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc, heads_cleared, live ? &lv : nullptr);
+    }
     else launch_hploc(s, d_boxes, d_skeys, key_bits, d_svals, n, d_nodes, d_leaves, c->hploc);
 }
 
@@ -164,7 +187,7 @@ void carve(bvh_ctx* c, char* base, uint32_t cap, size_t* total) {
     c->hploc.queue_capacity = hploc_queue_capacity(cap);
     c->hploc.queue_pc = k.take<u32>(c->hploc.queue_capacity);
     c->hploc.queue_rng = k.take<u64>(c->hploc.queue_capacity);
-    c->hploc.queue_count = k.take<u32>(64 * 32 + 32);      // (+ one word: sub-queue capacity for the LBVH tile scheduler)
+    c->hploc.queue_count = k.take<u32>(hploc_head_words());  // (the padded heads + the overlapped schedule's "tiles done" word)
     c->lbvh_queue_capacity = 2 * n > lbvh_queue_capacity(cap) ? 2 * n : lbvh_queue_capacity(cap);   // list0 doubles as the LBVH tile scheduler's root queue
     c->ploc.list0 = k.take<uint4>(c->lbvh_queue_capacity);
     c->ploc.list1 = k.take<uint4>(2 * n);
@@ -189,6 +212,9 @@ int ensure_capacity(bvh_ctx* c, uint32_t n) {
     carve(c, p, n, &total);
     HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)n * sizeof(u64), c->stream));   // HPLOC dependency words: clean once, builds keep them clean
     HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)n * sizeof(u32), c->stream));    // two-pass LBVH exchange words: likewise
+    HIP_TRY(hipMemsetAsync(c->hploc.queue_pc, 0, c->hploc.queue_capacity * sizeof(u32), c->stream));    // HPLOC queue slots (overlapped schedule: a slot is its own flag): likewise
+    HIP_TRY(hipMemsetAsync(c->hploc.queue_rng, 0, c->hploc.queue_capacity * sizeof(u64), c->stream));
+    c->queue_items_stale = false;
     return 0;
 }
 
@@ -197,6 +223,7 @@ int begin_emit(bvh_ctx* c) {
     if (c->scratch_dirty) {
         HIP_TRY(hipMemsetAsync(c->hploc.dep, 0, (size_t)c->cap * sizeof(u64), c->stream));
         HIP_TRY(hipMemsetAsync(c->flags, 0xFF, (size_t)c->cap * sizeof(u32), c->stream));
+        c->queue_items_stale = true;       // (a consumer that was cut short may have left items behind: the next overlapped build zeroes the slots)
     }
     c->scratch_dirty = true;
     return 0;
@@ -307,13 +334,15 @@ void bvh_abi_struct_sizes(uint32_t out[3]) { if (out) { out[0] = (uint32_t)sizeo
 int bvh_ctx_set_option(bvh_ctx* c, bvh_option option, int64_t value) {
     if (!c) return BVH_E_INVALID_ARG;
     switch (option) {
-        case BVH_OPT_HPLOC_SCHEDULER: case BVH_OPT_LBVH_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
-        case BVH_OPT_PLOC_SCHEDULER: if (value < 0 || value > 1) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_HPLOC_SCHEDULER: if (value < 0 || value > 3) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_LBVH_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; break;
+        case BVH_OPT_PLOC_SCHEDULER: if (value < 0 || value > 2) return BVH_E_INVALID_ARG; if (value == 2) value = 0; break;   // (2: ABI 4's cooperative launch, removed in round 5 — same trees; still accepted, means 0)
         case BVH_OPT_SORT_TEST_KNOBS: if (value & ~(int64_t)(8 | 32)) return BVH_E_INVALID_ARG; break;
         default: return BVH_E_INVALID_ARG;
     }
     c->options[(int)option] = value;
     c->sort.test_knobs = (int)c->options[BVH_OPT_SORT_TEST_KNOBS];
+    c->ploc.static_ids = c->options[BVH_OPT_PLOC_SCHEDULER] == 0;
     return 0;
 }
 #ifdef BVH_ABLATION   // measurement build only: raw reads of the HPLOC queue buffers (the upper half of queue_rng doubles as a trace buffer: tools/ext_trace.py)
@@ -330,7 +359,7 @@ extern "C" int bvh_debug_read_queue(bvh_ctx* c, int which, size_t off_words, voi
 #endif
 int bvh_ctx_get_option(const bvh_ctx* c, bvh_option option, int64_t* value_out) {
 #ifdef BVH_ABLATION   // measurement build only: option 1000 = merge tasks the HPLOC tile kernel ran in the last build (tools/measure_task_share.py)
-    if (c && value_out && (int)option >= 1000 && (int)option < 1000 + 2046) {      // 1001..: the other measurement words of sub-queue 0's padded head (ABL_EXT_TIMING)
+    if (c && value_out && (int)option >= 1000 && (int)option < 1000 + 2046 + 32) {      // 1001..: the other measurement words of sub-queue 0's padded head (ABL_EXT_TIMING)
         u32 v = 0; Bind b(c->device);
         if (!c->hploc.queue_count || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->hploc.queue_count + 2 + ((int)option - 1000), 4, hipMemcpyDeviceToHost) != hipSuccess) return BVH_E_INTERNAL;
         *value_out = v; return 0;
@@ -355,6 +384,10 @@ int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
     else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { c->stream = nullptr; bvh_ctx_destroy(c); return -(int)e; } c->own_stream = true; }
     // (a failure from here on goes through bvh_ctx_destroy, which releases whatever exists: stream, events, pinned words)
     for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { e = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
+    // the overlapped HPLOC schedule's consumer stream; its events order streams only (no time stamps)
+    { hipError_t r = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking); if (r != hipSuccess) { c->side = nullptr; bvh_ctx_destroy(c); return -(int)r; }
+      r = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming); if (r != hipSuccess) { c->ev_fork = nullptr; bvh_ctx_destroy(c); return -(int)r; }
+      r = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming); if (r != hipSuccess) { c->ev_join = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
     { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocMapped); if (r != hipSuccess) { c->h_pinned = nullptr; bvh_ctx_destroy(c); return -(int)r; }
       void* dp = nullptr; r = hipHostGetDevicePointer(&dp, c->h_pinned, 0); if (r != hipSuccess) { bvh_ctx_destroy(c); return -(int)r; } c->d_pinned = static_cast<u32*>(dp); }
     // the build path's code objects are loaded here, once per process and device, not by a context's first build (first build of a fresh process at 262 144 triangles:
@@ -370,6 +403,9 @@ void bvh_ctx_destroy(bvh_ctx* c) {
     if (!c) return;
     Bind b(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->arena) hipFree(c->arena);
     if (c->tris) hipFree(c->tris);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -561,7 +597,7 @@ static int build_impl(bvh_ctx* c, bvh_algo algo, const bvh_build_input* in, uint
     PrepArgs prep;
     prep.hist = c->sort.hist; prep.hist_words = (u32)SORT_HIST_COPIES * SORT_HIST_STRIDE;
     prep.status = reinterpret_cast<uint4*>(c->sort.status); prep.status_vecs = (u32)(((size_t)passes * sort_tiles(n) * SORT_RADIX) / 4);
-    prep.counters = c->sort.counters; prep.extra = c->hploc.queue_count; prep.extra_words = 64 * 32;
+    prep.counters = c->sort.counters; prep.extra = c->hploc.queue_count; prep.extra_words = hploc_head_words();
     if (algo == BVH_PLOCPP) ploc_begin_prep(c->ploc, n, prep);       // (the stage entry point bvh_emit_ploc launches k_ploc_init instead)
     const bool explicit_reset = !c->scene_ready;
     c->scene_ready = false;

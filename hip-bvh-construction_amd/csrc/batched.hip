@@ -77,6 +77,7 @@ extern "C" int bvh_batch_create(int n_dev, const int* devs, bvh_batch** out) {
     int rc = 0;
     for (int d = 0; d < n_dev && !rc; ++d) {
         rc = bvh_ctx_create(devs[d], &b->lane(d, 0));
+        if (rc == 0) rc = bvh_ctx_set_option(b->lane(d, 0), BVH_OPT_PLOC_SCHEDULER, 1);     // lanes share the device: no reliance on co-residency (chunk tickets always)
         if (!rc && (hipSetDevice(devs[d]) != hipSuccess || hipEventCreate(&b->ev0[d]) != hipSuccess || hipEventCreate(&b->ev1[d]) != hipSuccess)) rc = BVH_E_INTERNAL;
     }
     if (!rc) { if (ncclCommInitAll(b->comms.data(), n_dev, devs) != ncclSuccess) rc = BVH_E_INTERNAL; else b->comm_ok = true; }
@@ -110,7 +111,7 @@ extern "C" int bvh_batch_build(bvh_batch* b, bvh_algo algo, const void* const* h
     int rc = batch_reserve_slots(b, slots); if (rc) return rc;
     const int lanes = slots < BATCH_LANES ? slots : BATCH_LANES;               // contexts (streams, host threads) per device in this call
     for (int d = 0; d < n_dev; ++d)
-        for (int k = 1; k < lanes; ++k) if (!b->lane(d, k)) { rc = bvh_ctx_create(b->devs[d], &b->lane(d, k)); if (rc) return rc; }
+        for (int k = 1; k < lanes; ++k) if (!b->lane(d, k)) { rc = bvh_ctx_create(b->devs[d], &b->lane(d, k)); if (rc == 0) rc = bvh_ctx_set_option(b->lane(d, k), BVH_OPT_PLOC_SCHEDULER, 1); if (rc) return rc; }
     // per-mesh output slots (only when the caller wants the trees kept): device d's meshes one after another in its output arena
     std::vector<size_t> off_nodes(n_meshes, 0), off_leaves(n_meshes, 0);
     if (rep->meshes) {

@@ -116,12 +116,16 @@ __device__ __forceinline__ Box box_gather(const bvh_aabb* p) {
     const float2 c = reinterpret_cast<const float2*>(p)[2];
     return { a.x, a.y, a.z, a.w, c.x, c.y };
 }
-// the bounds of a 64-byte Triangle record, with stage E's operations in stage E's order (stage_em.hip k_extents): the same bits as the box array holds
+// the bounds of a 64-byte Triangle record, with stage E's operations in stage E's order (stage_em.hip k_extents, including the clamp against the reset box:
+// an all-NaN or all-+inf axis keeps +-FltMax): the same bits as the box array holds.  The clamps are integer-punned selects, not fminf / fmaxf: the emit kernels
+// are compiled with -fno-honor-nans, under which a float minimum against a constant may be folded away.
+__device__ __forceinline__ float clamp_lo_reset(float v) { return (v <= FMAX) ? v : FMAX; }        // fminf(FMAX, v): NaN and +inf -> FMAX
+__device__ __forceinline__ float clamp_hi_reset(float v) { return (v >= -FMAX) ? v : -FMAX; }      // fmaxf(-FMAX, v): NaN and -inf -> -FMAX
 __device__ __forceinline__ Box tri_box_gather(const float4* t) {
     const float4 a = t[0], b = t[1];
     const float c = reinterpret_cast<const float*>(t + 2)[0];
-    return { fminf(fminf(a.x, a.w), b.z), fminf(fminf(a.y, b.x), b.w), fminf(fminf(a.z, b.y), c),
-             fmaxf(fmaxf(a.x, a.w), b.z), fmaxf(fmaxf(a.y, b.x), b.w), fmaxf(fmaxf(a.z, b.y), c) };
+    return { clamp_lo_reset(fminf(fminf(a.x, a.w), b.z)), clamp_lo_reset(fminf(fminf(a.y, b.x), b.w)), clamp_lo_reset(fminf(fminf(a.z, b.y), c)),
+             clamp_hi_reset(fmaxf(fmaxf(a.x, a.w), b.z)), clamp_hi_reset(fmaxf(fmaxf(a.y, b.x), b.w)), clamp_hi_reset(fmaxf(fmaxf(a.z, b.y), c)) };
 }
 __device__ __forceinline__ Box box_load_u(const bvh_aabb* p) {
     const float* f = reinterpret_cast<const float*>(p);

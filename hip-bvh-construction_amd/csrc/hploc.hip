@@ -340,7 +340,9 @@ struct WaveList {            // k_hploc_ext: a wave's two 32-slot work lists wit
 };
 // One task per 32-lane half.  In: have / final_ (uniform per half), cnt, and the lane's cluster (tag, b; invalid beyond cnt) as loaded from the list.
 // Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
-template <bool AGENT, typename List, bool WIDE = false>
+// ZERO_WT (tile kernel of the overlapped schedule): the node stores that involve node 0 — node 0 itself and the node that points at it — are write-through although
+// AGENT is off: the root task of k_hploc_live, which runs while this launch's plain stores may still sit in an XCD's L2, reads node 0 and rewrites that link.
+template <bool AGENT, typename List, bool WIDE = false, bool ZERO_WT = false>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
                                                 const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
                                                 u32* rclk = nullptr) {
@@ -416,7 +418,7 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
                 }
                 at = 0u;
             } else if (l == 0u || r == 0u) st_agent(zero_parent, (at << 1) | (r == 0u ? 1u : 0u));   // who points at node 0
-            if (AGENT) node_store_agent(nodes + at, l, r, bu); else node_store_plain(nodes + at, l, r, bu);
+            if (AGENT || (ZERO_WT && (at == 0u || l == 0u || r == 0u))) node_store_agent(nodes + at, l, r, bu); else node_store_plain(nodes + at, l, r, bu);
         }
         b.lx = merge ? bu.lx : b.lx; b.ly = merge ? bu.ly : b.ly; b.lz = merge ? bu.lz : b.lz;
         b.hx = merge ? bu.hx : b.hx; b.hy = merge ? bu.hy : b.hy; b.hz = merge ? bu.hz : b.hz;
@@ -568,12 +570,19 @@ __global__ __launch_bounds__(HP_BLOCK, HPA_OCC) void k_hploc(const bvh_aabb* __r
 constexpr u32 HPQ_SUB = 64;        // sub-queues (a single queue head would serialise one atomic per block)
 constexpr u32 HPQ_LOCAL = 16;      // ready items a block aggregates in LDS before falling back to one atomic per item (typically 3-6; LDS: 7 blocks per CU need <= 23040 B each)
 
+// LIVE (overlapped schedule: k_hploc_live consumes the queue while the tile kernel fills it): a slot is its own flag — both words are zero before the build, each is written
+// once (pc + 1 and {L, R}: R >= 1, so neither is zero) by a write-through store, and the consumer that holds the slot's ticket takes the item when it has seen BOTH non-zero
+// and zeroes them again.  No order between the two stores is needed.
+template <bool LIVE = false>
 __device__ __forceinline__ void queue_put(u32* q_pc, u64* q_rng, u32 q_cap, u32 sub, u32 at_in_sub, u32 pc, u32 L, u32 R) {
     const size_t at = (size_t)sub * q_cap + at_in_sub;
-    q_pc[at] = pc; q_rng[at] = (u64)L | ((u64)R << 32);
+    if (LIVE) { if (at_in_sub < q_cap) { st_agent(q_pc + at, pc + 1u); st_agent(q_rng + at, (u64)L | ((u64)R << 32)); } }
+    else { q_pc[at] = pc; q_rng[at] = (u64)L | ((u64)R << 32); }
 }
+constexpr u32 HPQ_HEAD_WORDS = HPQ_SUB * 32u + 32u;  // words of queue_count a build clears: the padded heads + the line of HPQ_DONE_WORD
+constexpr u32 HPQ_DONE_WORD = HPQ_SUB * 32u;     // queue_count[HPQ_DONE_WORD]: tiles of the overlapped schedule that have handed over (cleared with the heads)
 
-template <typename K, int T, int NT, int OCC>
+template <typename K, int T, int NT, int OCC, bool LIVE = false>
 __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys,
                                                     const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
                                                     bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent,
@@ -606,6 +615,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     __shared__ u64 s_lvmask[2];                      // the non-empty levels (bit lv of word lv / 64): the level loop visits only those
     __shared__ u32 s_npub, s_nready, s_qbase, s_ncand;
     __shared__ u32 r_pc[HPQ_LOCAL], r_L[HPQ_LOCAL], r_R[HPQ_LOCAL];
+#ifndef HPB_LIVE_PAD
+#define HPB_LIVE_PAD 0   // overlapped schedule: extra LDS bytes per tile, so that fewer tiles fill a CU and k_hploc_live's workgroup finds room beside them
+#endif
+    __shared__ u32 s_livepad[LIVE && HPB_LIVE_PAD > 0 ? HPB_LIVE_PAD / 4 : 1];
+    if (LIVE && HPB_LIVE_PAD > 0 && n == 0xFFFFFFFFu) s_livepad[tid_x() % (HPB_LIVE_PAD > 0 ? HPB_LIVE_PAD / 4 : 1)] = 1u;      // (never true: keeps the allocation)
 #ifdef ABL_LDS_PAD       // in-situ probe: fewer workgroups per CU (is the kernel bound by latency x occupancy?)
     __shared__ u32 s_pad[ABL_LDS_PAD / 4];
     if (tid_x() == 0 && n == 0xFFFFFFFFu) s_pad[bid_x() % (ABL_LDS_PAD / 4)] = 1u;
@@ -830,7 +844,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false, TileList, HPB_WIDE != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], rclk_p);
+            ploc_rounds_lds<false, TileList, HPB_WIDE != 0, LIVE>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], rclk_p);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
         }
 #if defined(ABL_TILE_PHASES) && ABL_TILE_PHASES >= 2     // (2: also the waits at the levels' barriers — two more stamps per level)
@@ -857,7 +871,7 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     auto ready_push = [&](u32 pc, u32 L, u32 R) {
         const u32 at = atomicAdd(&s_nready, 1u);
         if (at < HPQ_LOCAL) { r_pc[at] = pc; r_L[at] = L; r_R[at] = R; }
-        else queue_put(q_pc, q_rng, q_cap, sub, atomicAdd(q_count + sub * 32u, 1u), pc, L, R);   // (pathological tiles only)
+        else queue_put<LIVE>(q_pc, q_rng, q_cap, sub, atomicAdd(q_count + sub * 32u, 1u), pc, L, R);   // (pathological tiles only)
     };
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -899,8 +913,10 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
                 const u32 sp = Lr + (u32)sl;
                 TileList::Tag tg; Box b;
                 tl.load(sp, tg, b);
-                node_store_plain(recs + rec_base(!right, L, R) + sl, TileList::is_valid(tg) ? tl.id(tg) : INV, tl.rep(tg), b);     // read by k_hploc_ext: the kernel boundary orders it
+                if (LIVE) node_store_agent(recs + rec_base(!right, L, R) + sl, TileList::is_valid(tg) ? tl.id(tg) : INV, tl.rep(tg), b);   // read by k_hploc_live DURING this launch
+                else node_store_plain(recs + rec_base(!right, L, R) + sl, TileList::is_valid(tg) ? tl.id(tg) : INV, tl.rep(tg), b);     // read by k_hploc_ext: the kernel boundary orders it
             }
+            if (LIVE) drain_stores();                // (the wave's record stores are in memory before a count moves)
             if (on && sl == 0) {                     // lane 0 of each group moves the parent's count
                 const u32 q = right ? L - 1u : R;
                 u32 pL, pR;
@@ -916,8 +932,11 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     if (nready) {
         if (tid == 0) s_qbase = atomicAdd(q_count + sub * 32u, nready);
         __syncthreads();
-        for (u32 i = (u32)tid; i < nready; i += (u32)NT) queue_put(q_pc, q_rng, q_cap, sub, s_qbase + i, r_pc[i], r_L[i], r_R[i]);
+        for (u32 i = (u32)tid; i < nready; i += (u32)NT) queue_put<LIVE>(q_pc, q_rng, q_cap, sub, s_qbase + i, r_pc[i], r_L[i], r_R[i]);
     }
+    // (overlapped schedule) this tile has handed over: every reservation it made in a sub-queue's count has returned (the overflow path's before the barrier above, the
+    // block's own into s_qbase), so a consumer that reads "all tiles done" and THEN a count reads the count's final value
+    if (LIVE && tid == 0) __hip_atomic_fetch_add(q_count + HPQ_DONE_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef ABL_TILE_PHASES
     TILE_PHASE(5);
     if (tid == 0) {
@@ -956,8 +975,11 @@ __device__ __forceinline__ void ext_trace(u64* trace, u32* trace_count, u32 cap,
 #endif
 struct ExtCarry { u32 id, rep; Box b; int side; };    // a half's survivors after a task (slot = lane & 31 < 16); side (owner lane): 0 none, 1 = they are
                                                       // the LEFT child of the half's next task, 2 = the RIGHT child
-template <typename K>
-__device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, ExtCarry& cw, const K* __restrict__ skeys,
+// LIVE (k_hploc_live, running beside the tile kernel): a small child's leaves are staged from the box array through the sorted values like the tile kernel stages them —
+// both arrays are older than either launch —, not from the PrimRefs the tile kernel writes: the tile that owns a leaf may not have run yet, and its plain stores
+// are not visible across XCDs before its launch ends.
+template <typename K, bool LIVE = false>
+__device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, ExtCarry& cw, const K* __restrict__ skeys, const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals,
                                          const bvh_primref* leaves, bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent, u32 ni, int lane, u64* nn, const WaveList& wl, u32* prof = nullptr EXT_TRACE_ARGS) {
     const int half = lane >> 5, slot = lane & 31, hbase = half << 5;
 #ifdef ABL_EXT_TRACE
@@ -991,7 +1013,9 @@ __device__ __forceinline__ void ext_pass(bool& ready, u32& pc, u32& L, u32& R, E
     Box b = box_empty();
     if (carried) { id = cid; rep = crep; b = cb; }
     const bool leaf = have && !carried && c_len <= HP_HALF && s < c_len;
-    if (leaf) { rep = c_start + s; id = ni + rep; b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1)); }
+    if (leaf) { rep = c_start + s; id = ni + rep;
+                if (LIVE) b = box_gather(boxes + svals[rep]);
+                else b = box_load_u(reinterpret_cast<const bvh_aabb*>(reinterpret_cast<const float*>(leaves + rep) + 1)); }
     rec_wait(r0, r1);                                                                          // one wait for records, leaves and the parent's keys
     if (from_rec) { id = __float_as_uint(r0.x); rep = __float_as_uint(r0.y); b = { r0.z, r0.w, r1.x, r1.y, r1.z, r1.w }; }
     u32 q = INV;
@@ -1127,7 +1151,7 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
             if ((lane & 31) == 0 && !ready && !have_item && !pending && !dry) { tk = atomicAdd(head, 1u); pending = true; }
             const u64 rm = __ballot(ready);
             if (!rm) { if (__ballot(pending || have_item)) continue; break; }
-            ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl, prof EXT_TRACE_PASS);
+            ext_pass(ready, pc, L, R, cw, skeys, boxes, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl, prof EXT_TRACE_PASS);
         }
         return;
     }
@@ -1138,7 +1162,100 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
         u32 pc = 0, L = 0, R = 0;
         if (ready) { const size_t at = (size_t)sub * q_cap + idx; pc = q_pc[at]; const u64 rg = q_rng[at]; L = (u32)rg; R = (u32)(rg >> 32); }
         ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
-        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl, prof EXT_TRACE_PASS);
+        while (__ballot(ready)) ext_pass(ready, pc, L, R, cw, skeys, boxes, svals, leaves, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl, prof EXT_TRACE_PASS);
+    }
+}
+
+// =====================================================================================================================
+// Overlapped schedule (round 6; BVH_OPT_HPLOC_SCHEDULER = 3, NOT the default): the external climb runs BESIDE the tile kernel instead of behind it.
+// Measured slower on the MI355X at every shape tried (10 M emit 0.886-1.20 ms against 0.750, 2 M 0.257 against 0.224; LEADS.md row 87, profiles/r06_live_timeline.md):
+// the tile kernel leaves no idle issue slots for the climb to hide in — with the consumers resident it runs 0.70-0.83 ms instead of 0.56, more than the ~0.095 ms of
+// bulk work it absorbs.  Kept as a selectable schedule with identical trees (tests/test_gpu_round6.py), like the other measured-and-dropped formulations.
+//
+// k_hploc_live is launched on a second stream as a small resident grid (HPL_GRID workgroups of 256 threads) whose half-waves take tickets in the 64 sub-queues and
+// poll their slot until the tile kernel has filled it (queue_put<LIVE>: a slot is its own flag), run the node and climb exactly like k_hploc_ext.  The tile kernel
+// never waits for this kernel, so whatever the dispatcher does with the two launches there is no cycle: a consumer only ever waits for tiles, and tiles only need a
+// free slot on some CU.  A consumer retires when every tile has handed over (queue_count[HPQ_DONE_WORD] == ntiles), its sub-queue's count — final by then — does not
+// reach its ticket, and it is not climbing; the wave that completes the root ends the build.  The idea: only the chain above the LAST tiles stays visible.
+// What crosses between the two running launches: the tiles' survivor records and queue items (write-through stores, drained before the dependency word moves),
+// node 0 and the node that points at it (ploc_rounds_lds<ZERO_WT>), the dependency words (agent-scope atomics on both sides).  Leaves: see ext_pass<LIVE>.
+// A watchdog on the 100 MHz clock ends a consumer that saw no progress for HPL_WATCHDOG_TICKS (a tile kernel that never came: a failed launch, a reset) — the build is
+// wrong then, but the device is not hung.
+// =====================================================================================================================
+#ifndef HPL_OCC
+#define HPL_OCC 6        // launch bound (waves per SIMD) of k_hploc_live: the register budget of k_hploc_ext
+#endif
+#ifndef HPL_GRID
+#define HPL_GRID 256u    // workgroups (a multiple of 16: waves are dealt to the 64 sub-queues round-robin)
+#endif
+#ifndef HPL_SLEEP
+#define HPL_SLEEP 24     // s_sleep argument of an idle wave's poll (64 clocks each)
+#endif
+constexpr u64 HPL_WATCHDOG_TICKS = 400000000ull;       // 4 s of the 100 MHz clock
+constexpr u32 HPL_POISON = 0xFFFFFFFFu;                // a slot's pc word: "the queue ended before this ticket" (pc + 1 of a real item is < 2^30)
+// Ending.  Nobody polls the "tiles done" word but ONE wave (the monitor: wave 0 of workgroup 0, which takes no tasks): 2048 half-waves polling one word saturate its
+// memory channel and with it everything else that maps there — the first build of this schedule ran the tile kernel three times slower for it.  When every tile has
+// handed over the sub-queues' counts are final; the monitor then poisons, in every sub-queue, as many slots behind the count as the sub-queue has consumers.  Tickets are
+// handed out in order and a consumer takes a new one only after its previous one was served, so every consumer ends its life on exactly one poisoned slot, which it zeroes
+// like any other: the slots are clean again when the launch ends.
+__device__ __forceinline__ u32 live_consumers(u32 nwaves, u32 sub) { return 2u * (nwaves / HPQ_SUB - (sub == 0u ? 1u : 0u)); }
+template <typename K>
+__global__ __launch_bounds__(256, HPL_OCC) void k_hploc_live(const bvh_aabb* __restrict__ boxes, const K* __restrict__ skeys, const u32* __restrict__ svals,
+                                                    bvh2_node* nodes, bvh2_node* recs, u64* dep, u32* zero_parent,
+                                                    u32* q_pc, u64* q_rng, u32* q_count, u32 q_cap, u32 n, u32 ntiles) {
+    __shared__ u64 s_nn[256 / WAVE][WAVE];
+    const int lane = tid_x() & (WAVE - 1);
+    const WaveList wl{ nullptr, nullptr, nullptr, nullptr };
+    const u32 nwaves = nbid_x() * (256 / WAVE);
+    const u32 wid = bid_x() * (256 / WAVE) + (u32)__builtin_amdgcn_readfirstlane((int)(tid_x() >> 6));
+    u64 t_last = __builtin_amdgcn_s_memrealtime();
+    if (wid == 0u) {     // the monitor
+        while (ld_agent(q_count + HPQ_DONE_WORD) != ntiles) {
+            if (__builtin_amdgcn_s_memrealtime() - t_last > HPL_WATCHDOG_TICKS) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        drain_stores();                                                       // (the counts are requested after "all tiles done" has arrived: they are final)
+        const u32 sub = (u32)lane;                                            // HPQ_SUB == WAVE: a sub-queue per lane
+        const u32 c = ld_agent(q_count + sub * 32u), m = live_consumers(nwaves, sub);
+#ifdef BVH_ABLATION      // measurement build: items queued and tickets taken at the moment the last tile handed over (words 1 / 2 behind the "tiles done" word; tools/ab_live.py)
+        atomicAdd(q_count + HPQ_DONE_WORD + 1u, c); atomicAdd(q_count + HPQ_DONE_WORD + 2u, ld_agent(q_count + sub * 32u + 1u));
+#endif
+        for (u32 k = 0; k < m; ++k) if (c + k < q_cap) st_agent(q_pc + (size_t)sub * q_cap + c + k, HPL_POISON);
+        return;
+    }
+    static_assert(HPQ_SUB == (u32)WAVE, "the monitor deals one sub-queue to each lane");
+    const u32 sub = wid % HPQ_SUB;
+    u32* const head = q_count + sub * 32u + 1u;
+    const bool owner_lane = (lane & 31) == 0;
+    bool ready = false, dry = false, ticket = false;
+    u32 pc = 0, L = 0, R = 0, tk = 0, ipc = 0;
+    ExtCarry cw; cw.id = INV; cw.rep = INV; cw.b = box_empty(); cw.side = 0;
+    while (true) {
+        if (owner_lane && !ready && !dry) {
+            if (!ticket) { tk = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ticket = true; ipc = 0u; }
+            if (tk >= q_cap) dry = true;                                      // (cannot happen: the capacity covers every item a build can queue, and then some)
+            else {
+                const size_t at = (size_t)sub * q_cap + tk;
+                if (ipc == 0u) ipc = ld_agent(q_pc + at);
+                if (ipc == HPL_POISON) { st_agent(q_pc + at, 0u); dry = true; }
+                else if (ipc != 0u) {
+                    const u64 irg = ld_agent(q_rng + at);                     // (the item's two words are independent stores: both must have landed)
+                    if (irg != 0ull) {
+                        st_agent(q_pc + at, 0u); st_agent(q_rng + at, 0ull);  // the slot is clean for the next build
+                        pc = ipc - 1u; L = (u32)irg; R = (u32)(irg >> 32); ready = true; ticket = false;
+                    }
+                }
+            }
+        }
+        const u64 rm = __ballot(ready);
+        if (!rm) {
+            if (!__ballot(owner_lane && !dry)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t_last > HPL_WATCHDOG_TICKS) break;
+            __builtin_amdgcn_s_sleep(HPL_SLEEP);
+            continue;
+        }
+        ext_pass<K, true>(ready, pc, L, R, cw, skeys, boxes, svals, nullptr, nodes, recs, dep, zero_parent, n - 1, lane, s_nn[tid_x() / WAVE], wl);
+        t_last = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1177,20 +1294,38 @@ static void hpb_config(int* t, int* nt, int* occ) {
 }
 uint32_t hploc_block_tile() { int t, nt, occ; hpb_config(&t, &nt, &occ); return (uint32_t)t; }
 // every tile may queue up to 2T nodes (its own external nodes + the parents of its maximal local ones), tiles >= 128 leaves
+uint32_t hploc_head_words() { return HPQ_HEAD_WORDS; }
 size_t hploc_queue_capacity(uint32_t n) { return (((size_t)n / 128 + 1) / HPQ_SUB + 6) * 2 * 128 * HPQ_SUB; }
 
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared) {
-    if (!heads_cleared) (void)hipMemsetAsync(sc.queue_count, 0, HPQ_SUB * 32 * sizeof(u32), s);
+                        void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared, const HplocLive* live) {
+    if (!heads_cleared) (void)hipMemsetAsync(sc.queue_count, 0, HPQ_HEAD_WORDS * sizeof(u32), s);
     int t, nt, occ; hpb_config(&t, &nt, &occ);
     const int dbg = hploc_ablation();
     const u32 q_cap = (u32)(sc.queue_capacity / HPQ_SUB);
-#define HPB_LAUNCH(KK, TT, NN, OO) hipLaunchKernelGGL((k_hploc_block<KK, TT, NN, OO>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
+#define HPB_LAUNCH(KK, TT, NN, OO, LL) hipLaunchKernelGGL((k_hploc_block<KK, TT, NN, OO, LL>), dim3((n + TT - 1) / TT), dim3(NN), 0, s, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
                        (bvh_primref*)d_leaves, (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, dbg, (const float4*)sc.leaf_tris)
+    if (live && live->side && !dbg && !(t == 1024 && nt == 512)) {
+        // overlapped schedule: the consumer grid goes to the side stream behind everything enqueued on s so far (the sort), the tile kernel to s; s then waits for the consumer
+        const u32 ntiles = (n + (u32)HPB_T - 1u) / (u32)HPB_T;
+        KernelScope ks(s, "k_hploc_block");
+        if (hipEventRecord(live->fork, s) != hipSuccess || hipStreamWaitEvent(live->side, live->fork, 0) != hipSuccess) return;
+        // the tile kernel first: a consumer grid whose producer was refused would only end by its watchdog
+        if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC64, true); else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC, true);
+        if (hipPeekAtLastError() != hipSuccess) return;
+#define HPL_LAUNCH(KK) hipLaunchKernelGGL((k_hploc_live<KK>), dim3(HPL_GRID), dim3(256), 0, live->side, (const bvh_aabb*)d_boxes, (const KK*)d_skeys, d_svals, \
+                       (bvh2_node*)d_nodes, (bvh2_node*)sc.recs, sc.dep, sc.zero_parent, sc.queue_pc, sc.queue_rng, sc.queue_count, q_cap, n, ntiles)
+        if (key_bits == 64) HPL_LAUNCH(u64); else HPL_LAUNCH(u32);
+#undef HPL_LAUNCH
+        (void)hipEventRecord(live->join, live->side);
+        KernelScope ks2(s, "k_hploc_live(tail)");      // (per-kernel events: from the tile kernel's end to the consumer's)
+        (void)hipStreamWaitEvent(s, live->join, 0);
+        return;
+    }
     { KernelScope ks(s, "k_hploc_block");
-      if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC64);
-      else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, HPB_OCC_1024);
-      else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC); }
+      if (key_bits == 64) HPB_LAUNCH(u64, HPB_T, HPB_NT, HPB_OCC64, false);
+      else if (t == 1024 && nt == 512) HPB_LAUNCH(u32, 1024, 512, HPB_OCC_1024, false);
+      else HPB_LAUNCH(u32, HPB_T, HPB_NT, HPB_OCC, false); }
 #undef HPB_LAUNCH
     if (dbg) return;
     KernelScope ks(s, "k_hploc_ext");

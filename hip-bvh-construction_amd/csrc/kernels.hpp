@@ -37,8 +37,7 @@ void launch_extents(hipStream_t s, const void* d_tris, uint32_t n, void* d_boxes
 void launch_extents_packed(hipStream_t s, const void* d_tris36, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
 void launch_extents_indexed(hipStream_t s, const void* d_vertices, const void* d_indices, uint32_t n_vertices, uint32_t n, void* d_boxes, void* d_scene, bool reset_scene = true, const PrepArgs* prep = nullptr);
 void launch_morton(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint32_t* d_keys, uint32_t* d_vals,
-                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes, float* d_reset_next = nullptr /* Aabb::reset of another extent (the next build's) */,
-                   uint32_t* d_p0_rows = nullptr /* cost probe of -DMORTON_P0_ROWS builds only (stage_em.hip) */);
+                   uint32_t* d_hist /*may be null*/, int hist_bits, int passes, float* d_reset_next = nullptr /* Aabb::reset of another extent (the next build's) */);
 // extended Morton code with a 60-bit budget in u64 keys (total_bits = 30 reproduces launch_morton's codes: the parity pin)
 void launch_morton64(hipStream_t s, const void* d_boxes, uint32_t n, const void* d_scene, uint64_t* d_keys, int total_bits,
                      uint32_t* d_hist /*may be null*/, int passes, float* d_reset_next = nullptr);
@@ -114,23 +113,29 @@ struct HplocScratch {
     uint32_t* zero_parent;   // u32[1]
     uint32_t* queue_pc;      // u32[queue_capacity]   (block-local mode: nodes ready for k_hploc_ext)
     uint64_t* queue_rng;     // u64[queue_capacity]
-    uint32_t* queue_count;   // u32[64 * 32]          (one padded head per sub-queue)
+    uint32_t* queue_count;   // u32[64 * 32 + 32]     (one padded head per sub-queue + the overlapped schedule's "tiles done" word)
     size_t    queue_capacity;
     const void* leaf_tris = nullptr;   // build path, 64-byte triangles only: the emitters stage a leaf's box from its triangle (one aligned 64-byte line per
                                        // leaf) instead of from the 24-byte box array (a box straddles two 64-byte lines one time in four); nullptr: boxes
 };
 size_t hploc_queue_capacity(uint32_t n);
 uint32_t hploc_block_tile();
+uint32_t hploc_head_words();     // words of queue_count every build starts from zero (the build path's first kernel clears them)
+// Overlapped schedule of the tile scheduler (hploc.hip "k_hploc_live"): the external climb runs on `side` beside the tile kernel.  queue_pc / queue_rng must be
+// all-zero before the build and are left all-zero by it (the classic schedule leaves its items behind: api.hip keeps track).
+struct HplocLive { hipStream_t side; hipEvent_t fork, join; };
 void launch_hploc(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
                   void* d_nodes, void* d_leaves, const HplocScratch& sc);
 void launch_hploc_block(hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const uint32_t* d_svals, uint32_t n,
-                        void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared = false /* sc.queue_count is already zero */);
+                        void* d_nodes, void* d_leaves, const HplocScratch& sc, bool heads_cleared = false /* sc.queue_count is already zero */,
+                        const HplocLive* live = nullptr /* non-null with a side stream: the overlapped schedule */);
 struct PlocScratch {
     void*     list0;         // 32-byte cluster entries {id, box} x n (ping)
     void*     list1;         // pong
     uint32_t* ids1;          // u32[n]
     uint64_t* status;        // u64[PLOC_MAX_ITERS * chunks]
     uint32_t* state;         // u32[PLOC_STATE_WORDS]
+    bool      static_ids = true;   // grids of <= 256 workgroups take chunk = workgroup id (no ticket); false: tickets always (BVH_OPT_PLOC_SCHEDULER 1: hosts that share the device)
 };
 constexpr int PLOC_CHUNK = 1024;
 constexpr int PLOC_MAX_ITERS = 96;

@@ -212,7 +212,7 @@ template <int PL_BLOCK, bool FIRST>
 __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restrict__ list_in, float4* __restrict__ list_out, bvh2_node* __restrict__ nodes,
                                                u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
                                                const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves,
-                                               const u32 wg, const u32 G) {
+                                               const u32 wg, const u32 G, const bool static_ok) {
     constexpr int PL_CPT = PLOC_CHUNK / PL_BLOCK;  // clusters per thread in the merge phase
     constexpr int SPT = (PL_SPAN + PL_BLOCK - 1) / PL_BLOCK;
     const int tid = tid_x();
@@ -222,7 +222,10 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
     // iteration's ~7 us.  Used when the grid turns out to cover the iteration's chunks (G >= chunks: every late iteration, every iteration below 256 chunks); the
     // speculative entries of positions beyond the count are masked like any halo position.  Otherwise the ticket path runs unchanged.
     u32 sid_[SPT]; Box sb_[SPT];
-    const bool spec = !FIRST && PL_BLOCK == 1024 && G <= (u32)PLOC_STATIC_G;       // (the 512-thread shape serves the early iterations of large inputs: thousands of chunks)
+    // static_ok: the host's word that this launch has the device to itself (api.hip: BVH_OPT_PLOC_SCHEDULER 0).  The look-back below spins on the predecessors' status words
+    // and has no helping path: with tickets a predecessor chunk is always held by a workgroup that is already running; with static ids it is held by a LOWER workgroup id,
+    // which the hardware dispatches first — true on this chip, but nothing a host that shares the device (the batched builder's lanes, CU masks) should have to rely on.
+    const bool spec = !FIRST && PL_BLOCK == 1024 && static_ok && G <= (u32)PLOC_STATIC_G;       // (the 512-thread shape serves the early iterations of large inputs: thousands of chunks)
     if (spec) {
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
@@ -305,7 +308,7 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
 
     // ---- one global iteration (Ploc :211-362), persistent over chunk tickets.  A chunk's compacted output needs the totals of all
     // chunks before it; instead of waiting for them the workgroup publishes its own totals, keeps the chunk's results in registers
-    // (PLOC_DEFER) and takes the next chunk — the walk over the predecessors' totals and the stores happen one chunk later, when
+    // and takes the next chunk — the walk over the predecessors' totals and the stores happen one chunk later, when
     // those totals have long been published.
     const u32 chunks = (C + PLOC_CHUNK - 1) / PLOC_CHUNK;
     bool p_have = false; u32 p_chunk = 0, p_tot = 0, p_ex = 0;
@@ -364,7 +367,7 @@ __device__ __forceinline__ bool ploc_iter_body(PlocLds& s, const float4* __restr
         }
     };
     const bool stat = spec && G >= chunks;                 // (grid-uniform)
-    for (u32 trip = 0; ; ++trip) {
+    while (true) {
         u32 chunk;
         if (stat) chunk = wg;                             // (one trip: the one-shot rule below ends the loop)
         else {
@@ -456,9 +459,9 @@ template <int PL_BLOCK, bool FIRST>
 __global__ __launch_bounds__(PL_BLOCK, (PL_BLOCK == 512 ? PLOC_OCC : 4)) void k_ploc_iter(const float4* __restrict__ list_in, float4* __restrict__ list_out,
                                                         bvh2_node* __restrict__ nodes,
                                                         u64* status, u32* counts, u32* tickets, u32* iters_done, u32 ni,
-                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves) {
+                                                        const bvh_aabb* __restrict__ boxes, const u32* __restrict__ svals, bvh_primref* __restrict__ leaves, int static_ok) {
     __shared__ PlocLds s;
-    (void)ploc_iter_body<PL_BLOCK, FIRST>(s, list_in, list_out, nodes, status, counts, tickets, iters_done, ni, boxes, svals, leaves, bid_x(), nbid_x());
+    (void)ploc_iter_body<PL_BLOCK, FIRST>(s, list_in, list_out, nodes, status, counts, tickets, iters_done, ni, boxes, svals, leaves, bid_x(), nbid_x(), static_ok != 0);
 }
 
 // one launch clears the per-iteration bookkeeping (two memsets + a one-thread kernel before: three launch boundaries of ~2 us in front of every build)
@@ -502,7 +505,7 @@ void ploc_enqueue(hipStream_t s, const PlocScratch& sc, uint32_t n, void* d_node
         const float4* in = (const float4*)(even ? sc.list0 : sc.list1); float4* out = (float4*)(even ? sc.list1 : sc.list0);
         const bool f0 = fresh && k == first;
 #define PLOC_LAUNCH(BLK, FIRST) hipLaunchKernelGGL((k_ploc_iter<BLK, FIRST>), dim3(grid), dim3(BLK), 0, s, in, out, (bvh2_node*)d_nodes, sc.status + (size_t)k * chunks, \
-                                                   counts + k, tickets + k, done, n - 1, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves)
+                                                   counts + k, tickets + k, done, n - 1, (const bvh_aabb*)d_boxes, d_svals, (bvh_primref*)d_leaves, sc.static_ids ? 1 : 0)
         if (wide) { if (f0) PLOC_LAUNCH(1024, true); else PLOC_LAUNCH(1024, false); }
         else      { if (f0) PLOC_LAUNCH(PLOC_NARROW, true); else PLOC_LAUNCH(PLOC_NARROW, false); }
 #undef PLOC_LAUNCH

@@ -94,26 +94,36 @@ template <typename K> struct SortWide { static constexpr int NT = 512, IPT = SOR
 template <> struct SortWide<u64> { static constexpr int NT = 512, IPT = 10; };    // 5120-pair tiles, 68 KB: 8 passes at 10 M 0.656 (256 x 20) -> 0.610 ms; 512 x 8: 0.657, 512 x 12: 0.731
 // BITS: digit width of this instantiation's pass (6..8; a pass whose digit is narrower than BITS passes a smaller digit_mask).  Status rows keep their
 // SORT_RADIX-word stride; a pass only touches the first 2^BITS words of a row.
-// GATE (SORT_WIDE_FLAG_WORD, kernels.hpp): 1 = the build's narrow top pass, which leaves at once when the Morton kernel saw a code beyond the bit range this
-// pass sorts; 2 = the full-width pass enqueued behind it, which leaves at once when it did not.  ghist + SORT_RADIX is that word for the fourth pass.
-template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK, int BITS = SORT_BITS, int GATE = 0>
-__global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
-                                                         K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
-                                                         int shift, u32 digit_mask, const u32* __restrict__ ghist,
-                                                         u32* status, u32* tile_counter, int dbg) {
+// The tile's LDS (the kernel declares it once: the gated last pass holds two bodies, see k_onesweep)
+template <typename K, int TILE, int NW> struct SortLds {
+    u32 whist[NW][SORT_RADIX];       // per-wave digit counters (a body of BITS < 8 uses the first 2^BITS words of a row)
+    u32 binoff[SORT_RADIX];
+    u32 gbase[SORT_RADIX];
+    K keys[TILE];
+    u32 vals[TILE];
+    u64 wsum[NW];
+#ifdef BVH_ABLATION
+    u32 tile;                        // (ticket order of the measurement build)
+#endif
+};
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT, int BITS>
+__device__ __forceinline__ void onesweep_tile(SortLds<K, NT * IPT, NT / WAVE>& lds, const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                              K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
+                                              int shift, u32 digit_mask, const u32* __restrict__ ghist,
+                                              u32* status, u32* tile_counter, int dbg) {
     constexpr int RADIX = 1 << BITS;
     constexpr int NW = NT / WAVE, NDW = RADIX / WAVE;             // waves; waves that own digits (threads 0 .. RADIX-1: one digit each)
     constexpr int TILE = NT * IPT;                   // keys per workgroup
     static_assert(BITS >= 6 && BITS <= SORT_BITS && NT % RADIX == 0, "digit threads are whole waves");
-    __shared__ u32 s_whist[NW][RADIX];
-    __shared__ u32 s_binoff[RADIX];
-    __shared__ u32 s_gbase[RADIX];
+    u32 (&s_whist)[NW][SORT_RADIX] = lds.whist;
+    u32 (&s_binoff)[SORT_RADIX] = lds.binoff;
+    u32 (&s_gbase)[SORT_RADIX] = lds.gbase;
     using Rec = PairRec<K>;
-    __shared__ K s_keys[TILE];
-    __shared__ u32 s_vals[TILE];
-    __shared__ u64 s_wsum[NW];
+    K (&s_keys)[TILE] = lds.keys;
+    u32 (&s_vals)[TILE] = lds.vals;
+    u64 (&s_wsum)[NW] = lds.wsum;
 #ifdef BVH_ABLATION
-    __shared__ u32 s_tile;                           // (ticket order of the measurement build)
+    u32& s_tile = lds.tile;
 #endif
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -123,9 +133,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #else
 #define SORT_STAMP() do { } while (0)
 #endif
-    if (GATE == 2) { if (ghist[SORT_RADIX] == 0u) return; }      // (uniform; before anything is loaded or written)
-    u32 gate_word = 0u;
-    if (GATE == 1) gate_word = ghist[SORT_RADIX];                 // a scalar load that travels with the tile's key loads; tested behind them
     SORT_STAMP();                                    // 0: start
     // Tile id = workgroup id.  Decoupled look-back makes a tile wait for its predecessors' totals; with static ids that is only deadlock-free
     // if every predecessor is (or gets) resident, which HIP's dispatch order does not promise.  The usual cure — tile ids from an atomic
@@ -165,7 +172,6 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
             val[i] = IOTA ? (base + local) : (ok ? SORT_LD(vals_in + base + local) : 0u);
         }
     }
-    if (GATE == 1) { if (gate_word != 0u) return; }               // (uniform; nothing has been written yet)
 #ifdef BVH_ABLATION
     if (dbg & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -325,6 +331,21 @@ __global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, 
 #endif
 #undef SORT_STAMP
 }
+// GATED (the build's last u32 pass from SORT_WIDE_MIN_N keys on; SORT_WIDE_FLAG_WORD, kernels.hpp): ONE launch holds both bodies of the pass — the narrow [24, 30) one
+// (64 digit threads, 6 ballots per key) and the reference's [24, 32) one — and every workgroup takes the branch the word k_morton raised selects: a scalar load and a
+// scalar branch in front of the tile's loads.  (Round 5 enqueued two launches, each leaving at once when it was not its turn: + 4.8 us per build for the second one,
+// which is what the narrow pass saves.)  ghist + SORT_RADIX is that word for the fourth pass; BITS / digit_mask are the narrow body's.
+template <typename K, bool IOTA, bool IN_AOS, bool OUT_AOS, int IPT, int NT = SORT_BLOCK, int BITS = SORT_BITS, bool GATED = false>
+__global__ __launch_bounds__(NT) void k_onesweep(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                         K* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
+                                                         int shift, u32 digit_mask, const u32* __restrict__ ghist,
+                                                         u32* status, u32* tile_counter, int dbg) {
+    __shared__ SortLds<K, NT * IPT, NT / WAVE> lds;
+    if (GATED && ghist[SORT_RADIX] != 0u)
+        onesweep_tile<K, IOTA, IN_AOS, OUT_AOS, IPT, NT, SORT_BITS>(lds, keys_in, vals_in, keys_out, vals_out, n, shift, (u32)SORT_RADIX - 1u, ghist, status, tile_counter, dbg);
+    else
+        onesweep_tile<K, IOTA, IN_AOS, OUT_AOS, IPT, NT, BITS>(lds, keys_in, vals_in, keys_out, vals_out, n, shift, digit_mask, ghist, status, tile_counter, dbg);
+}
 
 #ifdef BVH_ABLATION
 __global__ void k_lb_report(u32* c, u32 tiles, int pass) {
@@ -411,14 +432,13 @@ static void sort_pairs_t(hipStream_t s, const SortScratch& sc, const K* keys_in,
         const int pdbg = dbg | (((dbg & 128) && last) ? 1 : 0);
 #define SWEEP_G(IOTA, INA, OUTA, BB, GG, MASK) do { if (wide) hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SortWide<K>::IPT, SortWide<K>::NT, BB, GG>), g, bw, 0, s, kin, vin, kout, vout, n, sh, MASK, h, st, tc, pdbg); \
                                   else      hipLaunchKernelGGL((k_onesweep<K, IOTA, INA, OUTA, SORT_NARROW_IPT, SORT_NARROW_NT, BB, GG>), g, bn, 0, s, kin, vin, kout, vout, n, sh, MASK, h, st, tc, pdbg); } while (0)
-#define SWEEP_B(IOTA, INA, OUTA, BB) SWEEP_G(IOTA, INA, OUTA, BB, 0, mask)
+#define SWEEP_B(IOTA, INA, OUTA, BB) SWEEP_G(IOTA, INA, OUTA, BB, false, mask)
 #define SWEEP(IOTA, INA, OUTA) SWEEP_B(IOTA, INA, OUTA, SORT_BITS)
         bool launched = false;
         if constexpr (sizeof(K) == 4) {
             if (last && !first && gated_narrow_top && w == 6 && p == 3 && start_bit == 0 && hist_ready) {
-                SWEEP_G(false, true, false, 6, 1, mask);                  // the build's [24, 30) pass ...
-                SWEEP_G(false, true, false, SORT_BITS, 2, 255u);         // ... or, when a code has bit 30 / 31 set, the reference's [24, 32) pass (same rows, same histogram)
-                launched = true;
+                SWEEP_G(false, true, false, 6, true, mask);               // the build's [24, 30) pass — or, when a code has bit 30 / 31 set, the reference's [24, 32) pass
+                launched = true;                                          // (same launch, same rows, same histogram)
             }
         }
         if (launched) { }

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(EM_BLOCK) void k_morton64(const bvh_aabb* __restric
 template <int HIST_BITS>
 __global__ __launch_bounds__(EM_BLOCK) void k_morton(const bvh_aabb* __restrict__ boxes, const float* __restrict__ scene,
                                                      u32* __restrict__ keys, u32* __restrict__ vals, u32 n,
-                                                     u32* __restrict__ hist, int passes, float* reset_next, u32* p0_rows = nullptr) {
+                                                     u32* __restrict__ hist, int passes, float* reset_next) {
     if (reset_next && blockIdx.x == 0 && threadIdx.x < 6) reset_next[threadIdx.x] = threadIdx.x < 3 ? FMAX : -FMAX;     // Aabb::reset of the NEXT build's extent
     __shared__ MortonPlan s_plan; __shared__ float s_lo[3], s_ext[3];
     constexpr int RADIX = HIST_BITS > 0 ? (1 << HIST_BITS) : 1;
@@ -412,11 +412,11 @@ void launch_morton_plan(hipStream_t s, const void* d_scene, int* d_out, int tota
 }
 
 void launch_morton(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, u32* d_keys, u32* d_vals,
-                   u32* d_hist, int hist_bits, int passes, float* d_reset_next, u32* d_p0_rows) {
+                   u32* d_hist, int hist_bits, int passes, float* d_reset_next) {
     const dim3 g(em_grid(n)), b(EM_BLOCK);
     KernelScope ks(s, "k_morton");
-    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes, d_reset_next, d_p0_rows);
-    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0, d_reset_next, (u32*)nullptr);
+    if (d_hist && hist_bits == 8)       hipLaunchKernelGGL(k_morton<8>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, d_hist, passes, d_reset_next);
+    else                                hipLaunchKernelGGL(k_morton<0>,  g, b, 0, s, (const bvh_aabb*)d_boxes, (const float*)d_scene, d_keys, d_vals, n, (u32*)nullptr, 0, d_reset_next);
 }
 
 void launch_morton64(hipStream_t s, const void* d_boxes, u32 n, const void* d_scene, uint64_t* d_keys, int total_bits, u32* d_hist, int passes, float* d_reset_next) {

@@ -44,12 +44,15 @@ void* bvh_ctx_stream(const bvh_ctx* ctx);
 /* Per-context options.  The library never reads environment variables: which scheduler a builder uses is decided by the input size unless
  * the host says otherwise here (tests and A/B measurements do).  Unknown option or value: BVH_E_INVALID_ARG, nothing changes. */
 typedef enum {
-    BVH_OPT_HPLOC_SCHEDULER = 0,   /* 0 auto (by n; default), 1 one asynchronous launch (k_hploc), 2 tile kernel + external climb (k_hploc_block / k_hploc_ext) */
+    BVH_OPT_HPLOC_SCHEDULER = 0,   /* 0 auto (by n; default), 1 one asynchronous launch (k_hploc), 2 tile kernel, then the external climb (k_hploc_block / k_hploc_ext),
+                                      3 tile kernel with the external climb running beside it on the context's side stream (k_hploc_block / k_hploc_live).  Same trees. */
     BVH_OPT_LBVH_SCHEDULER  = 1,   /* 0 auto (by n; default), 1 one-launch kernels (k_lbvh_single / k_karras + k_refit), 2 tile scheduler (k_lbvh_block / k_lbvh_ext) */
     BVH_OPT_SORT_TEST_KNOBS = 2,   /* bit mask, default 0; results are identical for every value.  8: tiles are handed out in reverse order; 32: threads help at
                                       the first empty poll (both force the one-sweep sort's helping path, which in-order dispatch never takes) */
-    BVH_OPT_PLOC_SCHEDULER  = 3    /* 0 auto (default: = 1), 1 one launch per iteration (device-side loop, single-workgroup tail).  (ABI 4 also took 2 = a cooperative
-                                      launch with the cluster list resident in LDS: measured slower in round 4, removed in round 5 — BVH_E_INVALID_ARG now.) */
+    BVH_OPT_PLOC_SCHEDULER  = 3    /* 0 auto (default): one launch per iteration (device-side loop, single-workgroup tail); iterations of at most 256 chunks take chunk =
+                                      workgroup id, which assumes that the hardware dispatches a grid's workgroups in id order (it does).  1: chunk tickets in every
+                                      iteration — no such assumption; for hosts that share the device between contexts (the batched builder sets it on its lanes).
+                                      Same trees.  (2 was a cooperative launch, removed in round 5: still accepted, means 0.) */
 } bvh_option;
 int  bvh_ctx_set_option(bvh_ctx* ctx, bvh_option option, int64_t value);
 int  bvh_ctx_get_option(const bvh_ctx* ctx, bvh_option option, int64_t* value_out);

@@ -1,5 +1,5 @@
 """GPU: a non-default build of the kernels (build/variants/libbvh_alt.so from __graft_entry__.build(): both ends of the neighbour selection by LDS atomics, whole-wave
-lone rounds, PLOC++'s round-1 tail search and its late iterations in one launch) produces the same trees as the oracle and as the production library — the A/B switches kept in the sources are not dead code."""
+lone rounds, PLOC++'s round-1 tail search, leaf boxes staged from the triangles) produces the same trees as the oracle and as the production library — the A/B switches kept in the sources are not dead code."""
 import json
 import os
 import subprocess
@@ -20,7 +20,8 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "o
 import bvh_pkg
 pkg = bvh_pkg.load(); ctx = pkg.Context(0)
 out = {"lib": pkg.LIB_PATH}
-for name, tris in (("uniform5000", pkg.meshgen.uniform(5000, 11)), ("sponza100k", pkg.meshgen.sponza_like(100_000, 3)), ("uniform2100000", pkg.meshgen.uniform(2_100_000, 5))):
+ff = pkg.meshgen.uniform(5000, 12); ff.view(np.uint8).reshape(len(ff), -1)[7, :] = 0xFF      # an all-NaN triangle: its box is the reset box (ADVICE r05: tri_box_gather)
+for name, tris in (("uniform5000", pkg.meshgen.uniform(5000, 11)), ("ff5000", ff), ("sponza100k", pkg.meshgen.sponza_like(100_000, 3)), ("uniform2100000", pkg.meshgen.uniform(2_100_000, 5))):
     n = len(tris)
     for mode in ("async", "block"):
         ctx.set_option("hploc", mode)
@@ -50,5 +51,5 @@ def test_alt_variant_builds_the_same_trees():
     assert os.path.samefile(alt.pop("lib"), ALT) and not os.path.samefile(prod.pop("lib"), ALT)
     assert prod == alt, {k: (prod[k], alt.get(k)) for k in prod if prod[k] != alt.get(k)}
     # (node numbering follows from the topology alone: equal checksums = equal node arrays; the production library's trees are checked against the oracle by the parity tests)
-    for name in ("uniform5000", "sponza100k", "uniform2100000"):
+    for name in ("uniform5000", "ff5000", "sponza100k", "uniform2100000"):
         assert prod[f"hploc/{name}/async"] == prod[f"hploc/{name}/block"]
