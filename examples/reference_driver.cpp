@@ -56,6 +56,16 @@ template <typename B> static int run(Context& context, std::vector<Triangle>& tr
         put(o, bvh.m_colorBuffer);
     }
     (void)bvh.d_flags.size();           // (src/TwoPassLbvh.h:27: the member exists; its view is empty here)
+    {   // a host that keeps ONE reference stage beside the mirror: the sort call of src/Hploc.cpp:63-81 on the builder's own key / value members.  d_mortonCodeValues.ptr()
+        // materialises the iota the build never wrote (IotaView); the result must be the build's own sorted arrays.
+        const u32 n = (u32)triangles.size();
+        DeviceArray<u32> keysOut, valsOut;
+        keysOut.resize(context.handle(), n); valsOut.resize(context.handle(), n);
+        if (!bvh.d_mortonCodeValues.ptr()) { std::cerr << "d_mortonCodeValues.ptr() is null\n"; return 4; }
+        check(bvh_sort_pairs(context.handle(), bvh.d_mortonCodeKeys.ptr(), bvh.d_mortonCodeValues.ptr(), n, keysOut.ptr(), valsOut.ptr(), 0, 32), "bvh_sort_pairs");
+        if (keysOut.getData() != bvh.d_sortedMortonCodeKeys.getData() || valsOut.getData() != bvh.d_sortedMortonCodeValues.getData()) { std::cerr << "kept sort stage differs\n"; return 4; }
+        std::cout << "kept sort stage: ok" << std::endl;
+    }
     return 0;
 }
 

@@ -98,16 +98,8 @@ inline bool hploc_use_block(const bvh_ctx* c, uint32_t n) {
     if (o == 2 || o == 3) return true;
     return n >= HPLOC_BLOCK_MIN_N;
 }
-// ... and from this size on the external climb runs beside the tile kernel on the side stream (k_hploc_live) instead of behind it
-#ifndef HPLOC_LIVE_MIN_N
-#define HPLOC_LIVE_MIN_N 800000
-#endif
-inline bool hploc_use_live(const bvh_ctx* c, uint32_t n) {
-    const int64_t o = c->options[BVH_OPT_HPLOC_SCHEDULER];
-    if (o == 2) return false;
-    if (o == 3) return true;
-    return n >= (uint32_t)HPLOC_LIVE_MIN_N;
-}
+// the overlapped schedule (k_hploc_live beside the tile kernel) only when the host asks for it: measured slower at every size (LEADS.md row 87)
+inline bool hploc_use_live(const bvh_ctx* c, uint32_t) { return c->options[BVH_OPT_HPLOC_SCHEDULER] == 3; }
 // HPLOC emit on the ctx's scratch (SetupClusters + HPloc, src/Hploc.cpp:83-121)
 void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves,
                 bool heads_cleared = false) {

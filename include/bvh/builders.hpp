@@ -12,7 +12,7 @@
 // src/Hploc.cpp:167-181); all print the reference's perf block to std::cout.
 // Differences, all documented in INTEGRATION.md:
 //   * d_* members are lightweight views (ptr()/size()/getData()) of ctx-owned device memory instead of Oro::GpuMemory; they stay valid
-//     until the next build on the same Context.  d_mortonCodeValues is never materialised (value i = i): its getData() returns the iota;
+//     until the next build on the same Context.  d_mortonCodeValues (value i = i) is materialised on the first ptr() call after a build; its getData() returns the iota;
 //   * Context owns a bvh_ctx (device + stream + arena) instead of an Orochi context; device selectable (reference: 0);
 //   * SinglePassLbvh keeps m_rootNodeIdx = the BVH2 root (the reference overwrites it with the BVH4 root 0 before the BVH2 traversal
 //     uses it, src/SinglePassLbvh.cpp:183 vs :265 — a reference bug); the BVH4 root is always 0;
@@ -96,15 +96,29 @@ private:
     bvh_ctx* m_ctx = nullptr; T* m_ptr = nullptr; size_t m_size = 0;
 };
 // d_mortonCodeValues: value i = i (src/CommonBlocksKernel.h:384); this pipeline produces the indices inside the first sort pass instead of
-// writing and re-reading 4 bytes per primitive, so there is no device array behind it
+// writing and re-reading 4 bytes per primitive, so the build leaves no device array behind it.  A host that keeps one of the reference's stages beside the
+// mirror hands `d_mortonCodeValues.ptr()` to it (Oro::RadixSort::sort's source values, src/Hploc.cpp:63-81): ptr() therefore materialises the iota on its first
+// call after a build — one allocation owned by the view (re-used by later builds of at most that size) and one upload — instead of returning null.
 class IotaView {
 public:
-    void bind(size_t n) { m_size = n; }
-    u32* ptr() const { return nullptr; }
+    IotaView() = default;
+    IotaView(const IotaView&) = delete; IotaView& operator=(const IotaView&) = delete;
+    ~IotaView() { if (m_ptr) bvh_dev_free(m_ctx, m_ptr); }
+    void bind(bvh_ctx* c, size_t n) {
+        if (m_ptr && (c != m_ctx || n > m_cap)) { bvh_dev_free(m_ctx, m_ptr); m_ptr = nullptr; m_cap = 0; }
+        m_ctx = c; m_size = n; m_filled = 0;
+    }
+    u32* ptr() const {
+        if (!m_size) return nullptr;
+        if (!m_ptr) { void* p = nullptr; check(bvh_dev_alloc(m_ctx, m_size * sizeof(u32), &p), "bvh_dev_alloc"); m_ptr = static_cast<u32*>(p); m_cap = m_size; m_filled = 0; }
+        if (m_filled < m_size) { const std::vector<u32> h = getData(); check(bvh_dev_upload(m_ctx, m_ptr, h.data(), m_size * sizeof(u32)), "bvh_dev_upload"); m_filled = m_size; }
+        return m_ptr;
+    }
     size_t size() const { return m_size; }
     std::vector<u32> getData() const { std::vector<u32> h(m_size); std::iota(h.begin(), h.end(), 0u); return h; }
 private:
-    size_t m_size = 0;
+    bvh_ctx* m_ctx = nullptr; size_t m_size = 0;
+    mutable u32* m_ptr = nullptr; mutable size_t m_cap = 0, m_filled = 0;      // (an iota of m_filled entries is a prefix of every longer one: a smaller rebuild keeps it)
 };
 // a device allocation owned by the builder object (the wide tree, the image buffers)
 template <typename T> class DeviceArray {
@@ -206,7 +220,7 @@ private:
         d_sortedMortonCodeValues.bind(c, r.d_sorted_vals, n);
         d_mortonCodeKeys.bind(c, r.key_bits == 64 ? nullptr : r.d_morton_keys, r.key_bits == 64 ? 0 : n);
         d_mortonCodeKeys64.bind(c, r.key_bits == 64 ? r.d_morton_keys : nullptr, r.key_bits == 64 ? n : 0);
-        d_mortonCodeValues.bind(n);
+        d_mortonCodeValues.bind(c, n);
         m_rootNodeIdx = r.root; m_nInternalNodes = r.n_internal;
         m_timer.set(CalculateCentroidExtentsTime, t.ms_extents); m_timer.set(CalculateMortonCodesTime, t.ms_morton);
         m_timer.set(SortingTime, t.ms_sort); m_timer.set(BvhBuildTime, t.ms_build);

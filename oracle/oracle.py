@@ -403,6 +403,7 @@ def ref_driver(nofma: bool = False):
     L.refdrv_trace_while.argtypes = [vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32]
     L.refdrv_trace_kind.argtypes = [C.c_int, vp, vp, u32, vp, u32, vp, vp, vp, u32, u32, u32, u32]
     L.refdrv_extents.argtypes = [vp, u32, vp, vp]
+    L.refdrv_primref_frontend.argtypes = [vp, u32, vp, vp, vp]
     L.refdrv_ploc.argtypes = [vp, u32, vp, vp, vp, C.POINTER(u32), C.c_int]
     L.refdrv_collapse.argtypes = [C.c_int, vp, vp, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(u32)]
     rc = L.refdrv_init(os.path.join(_HERE, "_ref").encode(), int(nofma))
@@ -459,6 +460,16 @@ def ref_extents(tris, nofma=False):
     boxes = np.zeros(n, dtype=AABB); scene = np.zeros(1, dtype=AABB)
     _rc(L, L.refdrv_extents(tris.ctypes.data, n, boxes.ctypes.data, scene.ctypes.data), "refdrv_extents")
     return boxes, scene
+
+
+def ref_primref_frontend(primrefs, nofma=False):
+    """the reference's CalculatePrimRefExtents (src/CommonBlocksKernel.h:116-137, wave64 flavour) + CalculateMortonCodesPrimRef (:387-398) on the GPU, in the host order of
+    src/TwoPassLbvh.cpp:40-68 -> (scene Aabb, keys, values)"""
+    L = ref_driver(nofma); _reinit(L, nofma); n = primrefs.shape[0]
+    primrefs = np.ascontiguousarray(primrefs)
+    scene = np.zeros(1, dtype=AABB); keys = np.zeros(n, dtype=np.uint32); vals = np.zeros(n, dtype=np.uint32)
+    _rc(L, L.refdrv_primref_frontend(primrefs.ctypes.data, n, scene.ctypes.data, keys.ctypes.data, vals.ctypes.data), "refdrv_primref_frontend")
+    return scene, keys, vals
 
 
 def ref_ploc(boxes, svals, nofma=False, never_single_pass=False):

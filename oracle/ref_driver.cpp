@@ -145,6 +145,21 @@ int refdrv_extents(const void* h_tris, u32 n, void* h_boxes, void* h_scene) {
     return 0;
 }
 
+// The PrimRef flavours of the LBVH front end: CalculatePrimRefExtents (src/CommonBlocksKernel.h:116-137, wave64 flavour) + CalculateMortonCodesPrimRef (:387-398); host:
+// src/TwoPassLbvh.cpp:40-68, src/SinglePassLbvh.cpp:41-69 (extent reset to +-FltMax, both kernels launched over primitiveCount threads).  h_primrefs: PrimRef[n] as
+// Utility::doEarlySplitClipping leaves them when nothing is split (src/Utility.cpp:456-477: {i, Aabb grown over the three vertices}).
+int refdrv_primref_frontend(const void* h_primrefs, u32 n, void* h_scene, u32* h_keys, u32* h_vals) {
+    Dev<B28> refs; Dev<B24> scene; Dev<u32> keys, vals;
+    TRY(refs.alloc(n)); TRY(refs.up(h_primrefs)); TRY(scene.alloc(1)); TRY(keys.alloc(n, 0)); TRY(vals.alloc(n, 0));
+    const float fmax = 3.402823466e+38f; const float ext[6] = { fmax, fmax, fmax, -fmax, -fmax, -fmax };   // Aabb::reset(), src/Common.h:327-331
+    TRY(scene.up(ext));
+    { void* a[] = { &refs.p, &scene.p, &n }; TRY(launch(g_common64.m, "CalculatePrimRefExtents", n, 256, a)); }
+    { void* a[] = { &refs.p, &scene.p, &keys.p, &vals.p, &n }; TRY(launch(g_common.m, "CalculateMortonCodesPrimRef", n, 256, a)); }
+    RT(hipDeviceSynchronize());
+    TRY(scene.down(h_scene)); TRY(keys.down(h_keys)); TRY(vals.down(h_vals));
+    return 0;
+}
+
 // SetupClusters + the host loop of Ploc / SinglePassPloc (src/Ploc++Kernel.h:39-55,98-362, wave64 flavour); host: src/PLOC++Bvh.cpp:82-152 —
 // the three counters are cleared and the merged count read back (D2H) per iteration, the index buffers swap, below PlocBlockSize clusters one
 // SinglePassPloc launch finishes.  *iterations: passes of the loop.  never_single_pass: 0 = the reference's rule (SinglePassPloc below 1024

@@ -55,6 +55,7 @@ def test_reference_driver_runs_and_matches_ctypes_path(pkg, orc, ctx, driver, me
     r = subprocess.run([driver, which, mesh_files[mesh], dump], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     # the reference's perf block (src/TwoPassLbvh.cpp:300-310)
+    assert "kept sort stage: ok" in r.stdout      # d_mortonCodeValues.ptr() handed to a kept Oro::RadixSort::sort call site (src/Hploc.cpp:63-81) is a real device array
     for token in ("Perf Times", "CalculateCentroidExtentsTime :", "CalculateMortonCodesTime :", "SortingTime : ", "BvhBuildTime : ", "CollapseTime : ", "Bvh Cost : ", "Total Time : "):
         assert token in r.stdout
     tris = pkg.meshgen.load_tri(mesh_files[mesh]); n = len(tris)

@@ -81,8 +81,10 @@ def test_ctx_options_replace_env_knobs(pkg, orc, ctx):
     v = C.c_int64()
     for opt in range(4):
         assert L.bvh_ctx_get_option(ctx.handle, opt, C.byref(v)) == 0 and v.value == 0          # defaults: decide by size, no test knobs
-    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_HPLOC_SCHEDULER, 3) == -10001
-    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_PLOC_SCHEDULER, 2) == -10001             # 0 auto, 1 per-iteration launches (2, round 4's resident launch, was removed in round 5)
+    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_HPLOC_SCHEDULER, 4) == -10001            # 0 auto, 1 one launch, 2 tiles then climb, 3 tiles with the climb beside them (round 6)
+    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_PLOC_SCHEDULER, 3) == -10001
+    assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_PLOC_SCHEDULER, 2) == 0 and L.bvh_ctx_get_option(ctx.handle, pkg.OPT_PLOC_SCHEDULER, C.byref(v)) == 0 and v.value == 0
+    # (2, round 4's resident launch, was removed in round 5; an ABI-4 caller that still sets it gets the default — same trees — instead of an error: ADVICE r05)
     assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_PLOC_SCHEDULER, 0) == 0
     assert L.bvh_ctx_set_option(ctx.handle, pkg.OPT_SORT_TEST_KNOBS, 1) == -10001               # only the result-preserving knobs exist in the release library
     assert L.bvh_ctx_set_option(ctx.handle, 17, 0) == -10001 and L.bvh_ctx_get_option(ctx.handle, 17, C.byref(v)) == -10001

@@ -59,6 +59,32 @@ def test_reference_extents_kernel(pkg, orc, drv, ctx, kind, n, seed):
     assert d_scene.download(pkg.AABB, 1).tobytes() == scene_ref.tobytes()
 
 
+@pytest.mark.parametrize("kind,n,seed", [("cornell", 382, 0), ("uniform", 257, 3), ("flat", 2000, 8), ("sponza", 262_144, 3), ("bunny", 150_000, 2)])
+def test_reference_primref_frontend(pkg, orc, drv, ctx, kind, n, seed):
+    """the PrimRef flavours of the LBVH front end — CalculatePrimRefExtents (src/CommonBlocksKernel.h:116-137) and CalculateMortonCodesPrimRef
+    (:387-398), what src/TwoPassLbvh.cpp:48,66 and src/SinglePassLbvh.cpp:49,67 launch — on the MI355X, fed with the PrimRef array Utility::doEarlySplitClipping leaves
+    when nothing is split (src/Utility.cpp:456-477): scene extent and Morton keys == the product's front end (stage E + stage M), byte for byte, at config 2's and
+    config 1's sizes.  (This implementation keeps the PrimRefs on the device: SURVEY.md §8(d).)"""
+    tris = mesh(pkg, kind, n, seed); n = len(tris)
+    boxes, scene_o = orc.prim_bounds(tris)
+    refs = np.zeros(n, dtype=orc.PRIMREF); refs["prim"] = np.arange(n, dtype=np.uint32); refs["min"] = boxes["min"]; refs["max"] = boxes["max"]
+    scene_ref, keys_ref, vals_ref = orc.ref_primref_frontend(refs)
+    assert scene_ref.tobytes() == scene_o.tobytes(), "CPU oracle scene extent != reference CalculatePrimRefExtents"
+    assert np.array_equal(vals_ref, np.arange(n, dtype=np.uint32))
+    L = pkg.lib()
+    d_tris = ctx.upload(np.ascontiguousarray(tris)); d_box = ctx.alloc(n * 24); d_scene = ctx.alloc(32); d_keys = ctx.alloc(n * 4); d_vals = ctx.alloc(n * 4)
+    assert L.bvh_stage_extents(ctx.handle, d_tris.ptr, n, d_box.ptr, d_scene.ptr) == 0
+    assert L.bvh_stage_morton(ctx.handle, d_box.ptr, n, d_scene.ptr, d_keys.ptr, d_vals.ptr) == 0
+    assert d_scene.download(pkg.AABB, 1).tobytes() == scene_ref.tobytes()
+    assert np.array_equal(d_keys.download(np.uint32, n), keys_ref), "product Morton keys != reference CalculateMortonCodesPrimRef"
+    assert np.array_equal(d_vals.download(np.uint32, n), vals_ref)
+    # ... and the build path's own keys (the Morton kernel fused with the sort's histograms)
+    b = pkg.SinglePassLbvh().build(ctx, tris)
+    got = b.download()
+    order = np.argsort(keys_ref, kind="stable")
+    assert np.array_equal(got["sorted_keys"], keys_ref[order]) and np.array_equal(got["sorted_vals"], order.astype(np.uint32))
+
+
 PLOC_MESHES = [("cornell", 32, 0), ("cornell", 82, 0), ("cornell", 382, 0), ("probe", 5000, 0), ("probe", 50_000, 0),
                ("uniform", 2, 1), ("uniform", 3, 2), ("uniform", 1023, 31), ("uniform", 1024, 32), ("uniform", 1025, 33), ("uniform", 2049, 34), ("uniform", 4097, 5),
                ("dups", 3000, 9), ("flat", 2000, 8), ("sponza", 40_000, 3), ("bunny", 30_000, 2),
