@@ -1,6 +1,8 @@
 #!/bin/bash
+# Timeline of the overlapped HPLOC schedule per A/B build (profiles/r06_live_timeline.md): VARIANTS="l0 lc" TAG=x bash tools/prof_live.sh (on the GPU box, through gpurun)
+# — wall clock and stage times by tools/ab_live.py, then a rocprofv3 kernel trace of both streams (tools/kernel_timeline.py).  Variants: tools/build_variant.sh NAME "FLAGS".
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r6_b2_$TAG; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r6_live_$TAG; rm -rf $O; mkdir -p $O
 {
 for v in $VARIANTS; do
   lib=$R/build/variants/libbvh_$v.so
