@@ -18,7 +18,7 @@ def soak(pkg, orc, ctx, budget: float, seed: int, sizes=SIZES, max_random: int =
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     builds = 0; fails = []
-    saved = {k: ctx.get_option(k) for k in ("hploc", "lbvh")}
+    saved = {k: ctx.get_option(k) for k in ("hploc", "lbvh", "ploc")}
     try:
         while time.time() < t_end:
             n = int(rng.choice(sizes)) if rng.random() < 0.5 else int(np.exp(rng.uniform(np.log(2), np.log(max_random))))
@@ -30,9 +30,10 @@ def soak(pkg, orc, ctx, budget: float, seed: int, sizes=SIZES, max_random: int =
             d_tris = ctx.upload(tris)
             fe = orc.front_end(tris, morton_bits=bits) if n <= 1_200_000 else None
             for algo in (0, 1, 2, 3):
-                for mode in (("async", "single"), ("block", "block")) if algo != 2 else (("", ""),):
+                for mode in ((("async", "single"), ("block", "block"), ("live", "block")) if algo == 3 else (("async", "single"), ("block", "block"))) if algo != 2 else (("", ""),):
                     if time.time() > t_end + 30: break
                     ctx.set_option("hploc", mode[0] or "auto"); ctx.set_option("lbvh", mode[1] or "auto")
+                    if algo == 2: ctx.set_option("ploc", int(rng.integers(0, 2)))          # static chunk ids / tickets only
                     b = pkg.BUILDERS[algo]().build_ex(ctx, n, tris=d_tris, morton_bits=bits); got = b.download()
                     ok = orc.validate_bvh2(got["nodes"], got["leaves"], got["root"], n, got["layout"]) == 0
                     k = got["sorted_keys"]; ok = ok and bool(np.all(k[1:] >= k[:-1]))
