@@ -104,6 +104,16 @@ inline bool hploc_use_live(const bvh_ctx* c, uint32_t) { return c->options[BVH_O
 void emit_hploc(bvh_ctx* c, hipStream_t s, const void* d_boxes, const void* d_skeys, int key_bits, const u32* d_svals, uint32_t n, void* d_nodes, void* d_leaves,
                 bool heads_cleared = false) {
     if (hploc_use_block(c, n)) {
+        // the overlapped schedule's consumer stream and its two ordering events (no time stamps) exist from the first build that asks for them (a hardware queue per
+        // context that never uses it would be one more for the batched builder's lanes to share)
+        if (hploc_use_live(c, n) && !c->side) {
+            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+            else if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+                if (c->ev_fork) { (void)hipEventDestroy(c->ev_fork); c->ev_fork = nullptr; }
+                (void)hipStreamDestroy(c->side); c->side = nullptr;
+            }
+            (void)hipGetLastError();       // (a failure falls back to the classic schedule: same trees)
+        }
         const bool live = hploc_use_live(c, n) && c->side;
         const HplocLive lv{ c->side, c->ev_fork, c->ev_join };
         if (live && c->queue_items_stale) {      // (only after a switch of schedules on one context, or a build that failed half-way)
@@ -376,10 +386,6 @@ int bvh_ctx_create_on_stream(int device, void* hip_stream, bvh_ctx** out) {
     else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { c->stream = nullptr; bvh_ctx_destroy(c); return -(int)e; } c->own_stream = true; }
     // (a failure from here on goes through bvh_ctx_destroy, which releases whatever exists: stream, events, pinned words)
     for (auto& e : c->ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) { e = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
-    // the overlapped HPLOC schedule's consumer stream; its events order streams only (no time stamps)
-    { hipError_t r = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking); if (r != hipSuccess) { c->side = nullptr; bvh_ctx_destroy(c); return -(int)r; }
-      r = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming); if (r != hipSuccess) { c->ev_fork = nullptr; bvh_ctx_destroy(c); return -(int)r; }
-      r = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming); if (r != hipSuccess) { c->ev_join = nullptr; bvh_ctx_destroy(c); return -(int)r; } }
     { hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (16 + PLOC_STATE_WORDS) * sizeof(u32), hipHostMallocMapped); if (r != hipSuccess) { c->h_pinned = nullptr; bvh_ctx_destroy(c); return -(int)r; }
       void* dp = nullptr; r = hipHostGetDevicePointer(&dp, c->h_pinned, 0); if (r != hipSuccess) { bvh_ctx_destroy(c); return -(int)r; } c->d_pinned = static_cast<u32*>(dp); }
     // the build path's code objects are loaded here, once per process and device, not by a context's first build (first build of a fresh process at 262 144 triangles:

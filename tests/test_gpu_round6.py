@@ -23,6 +23,15 @@ def test_overlapped_schedule_builds_the_same_tree(pkg, ctx, kind, n):
         with ctx.options(hploc=mode):
             got.append(pkg.HPLOC().build(ctx, tris).checksum())
     assert got == [ref] * len(got), [f"{g:016x}" for g in got]
+    # ... and the overlapped schedule is what ran (a context whose side stream could not be created falls back to the classic schedule)
+    with ctx.options(hploc="live"):
+        try:
+            ctx.set_profiling(2)
+            pkg.HPLOC().build(ctx, tris)
+            kt = ctx.kernel_times()
+        finally:
+            ctx.set_profiling(0)
+    assert "k_hploc_live(tail)" in kt and "k_hploc_ext" not in kt, kt
 
 
 def test_overlapped_schedule_60_bit_keys(pkg, ctx):
