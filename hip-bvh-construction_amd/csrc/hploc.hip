@@ -1169,8 +1169,8 @@ __global__ __launch_bounds__(256, HPX_OCC) void k_hploc_ext(const bvh_aabb* __re
 // =====================================================================================================================
 // Overlapped schedule (round 6; BVH_OPT_HPLOC_SCHEDULER = 3, NOT the default): the external climb runs BESIDE the tile kernel instead of behind it.
 // Measured slower on the MI355X at every shape tried (10 M emit 0.886-1.20 ms against 0.750, 2 M 0.257 against 0.224; LEADS.md row 87, profiles/r06_live_timeline.md):
-// the tile kernel leaves no idle issue slots for the climb to hide in — with the consumers resident it runs 0.70-0.83 ms instead of 0.56, more than the ~0.095 ms of
-// bulk work it absorbs.  Kept as a selectable schedule with identical trees (tests/test_gpu_round6.py), like the other measured-and-dropped formulations.
+// the tile kernel leaves no idle issue slots for the climb to hide in — with the consumers resident it runs 0.70-0.83 ms instead of 0.56: the ~0.135 ms of
+// VALU-bound climbing it absorbs (profiles/r06_ext_chain.md), and more.  Kept as a selectable schedule with identical trees (tests/test_gpu_round6.py), like the other measured-and-dropped formulations.
 //
 // k_hploc_live is launched on a second stream as a small resident grid (HPL_GRID workgroups of 256 threads) whose half-waves take tickets in the 64 sub-queues and
 // poll their slot until the tile kernel has filled it (queue_put<LIVE>: a slot is its own flag), run the node and climb exactly like k_hploc_ext.  The tile kernel
