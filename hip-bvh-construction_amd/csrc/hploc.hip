@@ -216,6 +216,39 @@ __device__ __forceinline__ int nn_search_wide(const Box& b, Box nb, u32 off, u32
     return (int)(u32)nn[lane];
 }
 
+// The same search for the tile kernel's INTERLEAVED lane layout (HPB_IL): lanes 0..15 of a half hold the task's even slots, lanes 16..31 the odd ones, and every lane
+// also reads o = the box of slot + 1 from the LDS list.  The box of slot + r is then a 16-lane ROW shift of b (r even: by r / 2) or of o (r odd: by (r - 1) / 2; r = 1: o
+// itself) — a DPP operand of the union's v_min / v_max, no data movement: the 48 v_mov_b32_dpp of the wave_shl chain are gone.  A shift that leaves the row reads 0; such
+// a pair has slot + r >= 32 >= cnt and is masked.  No branch around a candidate (the compiler would sink the union into it, and a DPP operand cannot follow a narrowed
+// EXEC mask): a pair that does not exist carries the largest finite f64 exponent word instead of its area — it never wins a minimum, neither the far end's LDS word (which
+// may be a word of the wave's other half, or one of the 8 pad words behind the last wave's) nor the lane's own v_min_f64.  nnh: the half's key words, BY SLOT.
+template <typename List>
+__device__ __forceinline__ int nn_search_il(const Box& b, const List& list, u32 opos, bool act, u32 cnt, int slot, u64* nnh) {
+    nnh[slot] = ~0ull;
+    const Box o = list.load_box(opos);
+    compiler_fence();
+    double own = __longlong_as_double(0x7FEFFFFFFFFFFFFFll);
+#define HP_IL_CAND(RR, SRC, K) { \
+        const Box n_ = (K) == 0 ? (SRC) : row_shl<((K) == 0 ? 1 : (K))>(SRC); \
+        const float ex = fmaxf(n_.hx, b.hx) - fminf(n_.lx, b.lx), ey = fmaxf(n_.hy, b.hy) - fminf(n_.ly, b.ly), ez = fmaxf(n_.hz, b.hz) - fminf(n_.lz, b.lz); \
+        const float half_area = ex * ey + ex * ez + ey * ez; \
+        const u32 ab = (act && (u32)(slot + (RR)) < cnt) ? __float_as_uint(half_area + half_area) : 0x7FEFFFFFu; \
+        atomicMin(reinterpret_cast<unsigned long long*>(nnh + slot + (RR)), ((unsigned long long)ab << 32) | (u32)slot); \
+        own = __builtin_fmin(own, __longlong_as_double((long long)(((unsigned long long)ab << 32) | (u32)(slot + (RR))))); }
+    HP_IL_CAND(2, b, 1) HP_IL_CAND(4, b, 2) HP_IL_CAND(6, b, 3) HP_IL_CAND(8, b, 4)
+    HP_IL_CAND(1, o, 0) HP_IL_CAND(3, o, 1) HP_IL_CAND(5, o, 2) HP_IL_CAND(7, o, 3)
+#undef HP_IL_CAND
+    compiler_fence();
+    const u64 left = nnh[slot];
+    const u64 right = (u64)__double_as_longlong(own);
+    const u32 choice = (u32)(left < right ? left : right);
+    // (ploc_rounds_lds reads the neighbour's choice from the low half of its key word.)  The WHOLE word is written, high half 0: the unmasked far-end atomics of the
+    // previous wave's upper half reach this wave's slots 0..7, unordered with this wave — an all-but-largest key arriving after the choice was left here must not win
+    nnh[slot] = (u64)choice;
+    compiler_fence();
+    return (int)choice;
+}
+
 // PLOC rounds (findNearestNeighbours + mergeClusters) until <= 16 clusters (root: 1) remain; the work list stays in
 // registers (w is updated in place).  AGENT: node stores are agent-scope write-through because other workgroups of the SAME launch
 // read them; the block kernel's nodes are only read by later launches and use plain (cached, write-combined) stores.
@@ -342,15 +375,16 @@ struct WaveList {            // k_hploc_ext: a wave's two 32-slot work lists wit
 // Out: cnt survivors, the lane's cluster of slot `slot`, and the list holding them at base + [0, cnt).  lim: highest valid list position (clamp).
 // ZERO_WT (tile kernel of the overlapped schedule): the node stores that involve node 0 — node 0 itself and the node that points at it — are write-through although
 // AGENT is off: the root task of k_hploc_live, which runs while this launch's plain stores may still sit in an XCD's L2, reads node 0 and rewrites that link.
-template <bool AGENT, typename List, bool WIDE = false, bool ZERO_WT = false>
+// IL: interleaved lane layout (nn_search_il): slot is NOT lane & 31; below_il = the half's lanes that hold lower slots.
+template <bool AGENT, typename List, bool WIDE = false, bool ZERO_WT = false, bool IL = false>
 __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt_io, typename List::Tag& tag_io, Box& b_io, u32 base, u32 nl, u32 rbase, u32 lim,
                                                 const List& list, bvh2_node* nodes, u32* zero_parent, int lane, int slot, int hbase, u64* nn,
-                                                u32* rclk = nullptr) {
+                                                u32* rclk = nullptr, u32 below_il = 0u) {
     // rclk (measurement build, ABL_ROUND_CLOCK): wave-uniform sums {wave-rounds, shader-clock ticks spent in them, active halves} — tools/round_clock.py
     typename List::Tag tag = tag_io;
     u32 cnt = cnt_io;
     Box b = b_io;
-    const u32 below = (1u << slot) - 1u;                  // the half's lanes that hold lower slots
+    const u32 below = IL ? below_il : (1u << slot) - 1u;  // the half's lanes that hold lower slots
     const u32 threshold = final_ ? 1u : HP_HALF;
     // a task that needs no round only left-packs its right child's clusters (done up front: a helping half's b does not survive the loop, HPB_WIDE)
     if (have && cnt <= threshold && (u32)slot >= nl && (u32)slot < cnt) list.store(base + (u32)slot, tag, b);
@@ -375,6 +409,9 @@ __device__ __forceinline__ void ploc_rounds_lds(bool have, bool final_, u32& cnt
             b = list.load_box(p0 < lim ? p0 : lim);
             const Box st = list.load_box(p1 < lim ? p1 : lim);
             nbr = (u32)nn_search_wide(b, st, off, a_cnt, ah + slot, slot, lane, nn) & 31u;
+        } else if (IL) {
+            const u32 p1 = (u32)slot + 1u < nl ? base + (u32)slot + 1u : rbase + (u32)slot + 1u;
+            nbr = (u32)nn_search_il(b, list, p1 < lim ? p1 : lim, act, cnt, slot, nn + hbase) & 31u;
         } else {
             const u32 raw = (u32)nn_search<true>(b, act, cnt, lane, slot, nn);
             nbr = raw & 31u;
@@ -592,6 +629,12 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
     static_assert(T % NT == 0 && T <= 16384, "block-local HPLOC tile");
     constexpr int NLEV = KeyBits<K>::value;          // hierarchy levels = bits of the augmented key (64 / 96)
     constexpr int KM = 18;                           // key margin: the hand-over probes up to 17 leaves beyond the tile's rims (small children of external
+#ifndef HPB_IL
+#define HPB_IL 1         // 1 (default since round 6): interleaved lane layout of the tile kernel's rounds (nn_search_il: the row shifts become DPP operands of v_min / v_max,
+                         //    no branch around a candidate: -45 VALU instructions and -8 scalar branches per round).  Round 3 measured it at nothing with both ends of a pair
+                         //    minimised by LDS atomics; with the own end in a register pair (HP_NN_LDS = 3) same box, three alternating pairs: 10 M 0.5690 -> 0.5600 ms,
+                         //    2 M 0.1389 -> 0.1367 (LEADS.md row 94).  0: the wave_shl chain of nn_search (the alt variant; HPB_WIDE needs it)
+#endif
 #ifndef HPB_WIDE
 #define HPB_WIDE 0       // A/B switch (off: measured, no gain — LEADS.md row 64).  1: a round in which only one half of the wave still has a task runs that task on the whole wave (nn_search_wide: four candidates per lane)
 #endif
@@ -839,12 +882,17 @@ __global__ __launch_bounds__(NT, OCC) void k_hploc_block(const bvh_aabb* __restr
             const u32 nl = (u32)__popc(vb & 0xFFFFu), nr = (u32)__popc(vb >> 16);
             u32 cnt = nl + nr;
             const u32 rbase = P + 1u - nl;
-            const int ts = slot;
+#if HPB_IL
+            const int ts = ((lane & 15) << 1) | ((lane >> 4) & 1);                               // the task slot this lane holds (interleaved layout: nn_search_il)
+            const u32 below_il = ((1u << ((lane & 15) + ((lane >> 4) & 1))) - 1u) | (((1u << (lane & 15)) - 1u) << 16);
+#else
+            const int ts = slot; const u32 below_il = 0u;
+#endif
             const u32 sp = (u32)ts < nl ? L + (u32)ts : rbase + (u32)ts;
             TileList::Tag tag; Box b;
             tl.load(sp < (u32)T ? sp : (u32)T - 1u, tag, b);
             if (!(have && (u32)ts < cnt)) tag = TileList::invalid_tag();
-            ploc_rounds_lds<false, TileList, HPB_WIDE != 0, LIVE>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], rclk_p);
+            ploc_rounds_lds<false, TileList, (HPB_WIDE != 0 && HPB_IL == 0), LIVE, HPB_IL != 0>(have, false, cnt, tag, b, L, nl, rbase, (u32)T - 1u, tl, nodes, zero_parent, lane, ts, hbase, s_nn[wave], rclk_p, below_il);
             if (have && (u32)ts >= cnt && ts < 16) tl.invalidate(L + (u32)ts);          // INVALID-terminated
         }
 #if defined(ABL_TILE_PHASES) && ABL_TILE_PHASES >= 2     // (2: also the waits at the levels' barriers — two more stamps per level)

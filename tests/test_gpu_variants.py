@@ -1,4 +1,4 @@
-"""GPU: a non-default build of the kernels (build/variants/libbvh_alt.so from __graft_entry__.build(): both ends of the neighbour selection by LDS atomics, whole-wave
+"""GPU: a non-default build of the kernels (build/variants/libbvh_alt.so from __graft_entry__.build(): both ends of the neighbour selection by LDS atomics on the wave_shl chain instead of the interleaved lane layout, whole-wave
 lone rounds, PLOC++'s round-1 tail search, leaf boxes staged from the triangles) produces the same trees as the oracle and as the production library — the A/B switches kept in the sources are not dead code."""
 import json
 import os
