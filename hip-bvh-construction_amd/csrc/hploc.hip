@@ -14,7 +14,8 @@
 //    the reference walks them with two global atomics per node just to discover them.
 //  * a merge task occupies one 32-lane half of a wave64: the work list (id, rep, box) lives in registers, neighbours come
 //    from DPP wave shifts, partners through ds_bpermute, compaction through ds_permute.  Two tasks run side by side in the
-//    two halves.  No barriers inside a task, no reliance on store conflict order.
+//    two halves.  No barriers inside a task, no reliance on store conflict order.  (The tile kernel keeps its
+//    lists in LDS instead — ploc_rounds_lds — on an interleaved lane layout whose neighbour boxes are row-shift DPP operands: nn_search_il.)
 //  * large inputs (k_hploc_block): a workgroup owns a tile of T consecutive sorted leaves and processes every node whose
 //    range lies inside the tile out of LDS, level by level; only the nodes that cross tile boundaries (the ancestors of the
 //    T-aligned gaps, ~15 % of the tasks at T = 512) use the inter-workgroup protocol below, in a second launch (k_hploc_ext).

@@ -2,7 +2,7 @@
 # per-launch durations of k_ploc_iter for one PLOC++ build size (rocprofv3 kernel trace): python-side analysis of the rocpd db
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; N=${1:-10000000}
-rocprofv3 --kernel-trace -d $R/gpurun_out/pl -- python $R/bench.py --algo ploc --mesh ${2:-uniform} --tris $N --steps 2 --warmup 1 --cpu-sample 0 --no-kernel-events > $R/gpurun_out/pl.log 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/pl -- python $R/bench.py --algo ploc --mesh ${2:-uniform} --tris $N --steps 2 --warmup 1 --cpu-sample 0 --no-kernel-events --no-secondary > $R/gpurun_out/pl.log 2>&1
 f=$(find $R/gpurun_out/pl -name "*.db" | head -1)
 python - "$f" <<'PY'
 import sqlite3, sys
