@@ -166,9 +166,9 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
                 // an entry's own candidates (s, s + r): running minimum of the same 64-bit key in a register pair — one v_min_f64 each (a non-negative f32 area as the
                 // high word makes the key a non-negative finite f64, which orders like its bit pattern; hploc.hip, HP_NN_LDS = 3) — and ONE atomic at the end
                 // (the entry's word also collects the keys of the pairs (s - r, s), from this and from other rows): 18 LDS atomics per lane and tile instead of 32.
-                // Only in the 1024-thread instantiation (lists below PLOC_NARROW_MIN chunks: 262 144 0.3744 -> 0.3693 ms); the 512-thread one runs at 96 VGPRs and
-                // would spill the two accumulators (10 M 2.158 -> 2.204 ms)
-                constexpr bool OWN = PLOC_NN_OWN_F64 && PL_BLOCK == 1024;
+                // Both instantiations since round 6: the 512-thread one spilled the two accumulators at 96 VGPRs (five waves per SIMD: 10 M 2.158 -> 2.204 ms); compiled for four
+                // (PLOC_OCC = 4: 106 VGPRs, no scratch) it gains (same box, LEADS.md row 96).  262 144 (1024-thread shape only) 0.3744 -> 0.3693 ms in round 5.
+                constexpr bool OWN = PLOC_NN_OWN_F64 != 0;
                 double ownA = __longlong_as_double(0x7FEFFFFFFFFFFFFFll), ownB = ownA;
                 auto cand = [&](const Box& nA, const Box& nB, const int r) {
                     const v2f_t lx = { fminf(nA.lx, bA.lx), fminf(nB.lx, bB.lx) }, ly = { fminf(nA.ly, bA.ly), fminf(nB.ly, bB.ly) }, lz = { fminf(nA.lz, bA.lz), fminf(nB.lz, bB.lz) };
@@ -202,7 +202,7 @@ __device__ __forceinline__ void nn_pairs_fn(PlocLds& s, const int tid, const int
 // FIRST: the build's first iteration reads the clusters straight from the sorted values and the primitive boxes and writes the
 // PrimRef leaves on the way — SetupClusters (:39-55) fused: the initial cluster list (32 B written + 32 B read per primitive) never exists.
 #ifndef PLOC_OCC
-#define PLOC_OCC 5
+#define PLOC_OCC 4       // waves per SIMD the 512-thread instantiation is compiled for (5 until round 6: 96 VGPRs)
 #endif
 #ifndef PLOC_STATIC_G
 #define PLOC_STATIC_G 256     // largest grid that takes static chunk ids (0: tickets always)

@@ -23,7 +23,7 @@ SETS = [
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DBVH_ABLATION", "-DABL_EXT_TIMING"]),
     # the overlapped schedule's shapes of profiles/r06_live_timeline.md (LEADS.md row 87)
     ("hploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DBVH_ABLATION", "-DHPB_LIVE_PAD=2560", "-DHPL_OCC=8", "-DHPL_GRID=1024u", "-DHPL_SLEEP=120"]),
-    ("ploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DPLOC_NN_OWN_F64=0", "-DPLOC_TAIL_PAIRS=0", "-DPLOC_ABL=1", "-DPLOC_OCC=4", "-DPLOC_STATIC_G=0"]),
+    ("ploc.hip", EMIT + ["-fno-slp-vectorize"], ["-DPLOC_NN_OWN_F64=0", "-DPLOC_TAIL_PAIRS=0", "-DPLOC_ABL=1", "-DPLOC_OCC=5", "-DPLOC_STATIC_G=0"]),
     ("sort.hip", [], ["-DBVH_ABLATION", "-DSORT_WIDE_IPT=12", "-DSORT_HELP_AFTER=64u"]),
     ("lbvh.hip", EMIT, ["-DLBVH_EXT_MAX_SHIFT=6", "-DBVH_ABLATION"]),
     ("api.hip", [], ["-DSORT_GATE_TOP=0", "-DBVH_ABLATION"]),
